@@ -1,0 +1,229 @@
+"""Golden-vector generator.  TEST INFRASTRUCTURE ONLY; runs in the BUILD CONTAINER ONLY.
+
+Imports the real reference from /root/reference (read-only, never copied), feeds it the
+deterministic tensors of `oracle/weights.py`, runs its PyTorch-CPU fp32 forward/backward and
+writes small fixtures under `tests/golden/`.  The reference cannot travel to the GPU box; the
+fixtures (data only: inputs by seed, expected outputs) are what pins the oracle there.
+
+  python oracle/gen_golden.py            # regenerates every fixture
+
+`transformer.py` imports as-is (torch + einops).  `train_vit.py` / `train_titok.py` /
+`train_vit_vqgan.py` import packages that are absent from this image (torchvision, wandb,
+lpips, vector_quantize_pytorch) at module top level but never touch them from the model classes
+(all loop code is under `__main__`); empty placeholder modules are registered for those names
+so the `import` statements succeed.  Nothing is taken from them.
+
+Each fixture also records the reference's OWN bf16-autocast deviation from its fp32 result
+(CPU autocast, same weights and inputs) so tolerances are judged against a measured floor.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+import weights as W  # noqa: E402
+from vit_oracle import rel_l2  # noqa: E402
+
+SAMPLE_STRIDE = 997  # prime; flattened tensors are sampled every 997th element
+
+
+def _placeholder(name, **attrs):
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import transformer as ref_transformer  # clean import, no placeholders needed
+
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tv.transforms)
+    sys.modules.setdefault("torchvision.models", tv.models)
+    _placeholder("wandb")
+    _placeholder("lpips")
+    _placeholder("vector_quantize_pytorch", FSQ=None)
+    import train_vit as ref_train_vit
+    import utils as ref_utils
+
+    return ref_transformer, ref_train_vit, ref_utils
+
+
+def sample(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().flatten()[::SAMPLE_STRIDE].clone().float()
+
+
+def summarize(t: torch.Tensor) -> dict:
+    t = t.detach().float()
+    return {"norm": float(t.double().norm()), "sample": sample(t), "shape": list(t.shape)}
+
+
+def save(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    torch.save(obj, path)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def run_fwd_bwd(model, x, dy, autocast_bf16=False):
+    model.zero_grad(set_to_none=True)
+    x = x.detach().clone().requires_grad_(True)
+    if autocast_bf16:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y = model(x)
+    else:
+        y = model(x)
+    (y.float() * dy).sum().backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    return y.detach().float(), x.grad.detach().clone(), grads
+
+
+# ------------------------------------------------------------------------------------------
+def gen_transformer_fixtures(RT):
+    # G1/G2/G5: tiny stacks, everything stored in full
+    for tag, causal in (("tiny", False), ("tiny_causal", True)):
+        L, H, D, N, B, seed = 2, 2, 128, 37, 3, 11
+        cfg = RT.TransformerConfig(n_layers=L, n_heads=H, n_embd=D, block_size=N, causal=causal)
+        model = RT.Transformer(cfg)
+        sd = W.transformer_state(seed, "", L, D, causal_block=N if causal else None)
+        model.load_state_dict(sd, strict=True)
+        x = W.normal(seed, "x", (B, N, D))
+        dy = W.normal(seed, "dy", (B, N, D))
+        y, dx, grads = run_fwd_bwd(model, x, dy)
+        y16, dx16, g16 = run_fwd_bwd(model, x, dy, autocast_bf16=True)
+        save(f"transformer_{tag}.pt", {
+            "cfg": {"n_layers": L, "n_heads": H, "n_embd": D, "seq": N, "batch": B, "seed": seed, "causal": causal},
+            "state_keys": sorted(model.state_dict().keys()),
+            "y": y, "dx": dx, "grads": grads,
+            "ref_bf16_floor": {"y": rel_l2(y16, y), "dx": rel_l2(dx16, dx),
+                               "grads": {k: rel_l2(g16[k], grads[k]) for k in grads}},
+        })
+
+    # one ViT-B layer at the real sequence length, summarised
+    L, H, D, N, B, seed = 1, 12, 768, 197, 2, 12
+    cfg = RT.TransformerConfig(n_layers=L, n_heads=H, n_embd=D, block_size=N)
+    model = RT.Transformer(cfg)
+    model.load_state_dict(W.transformer_state(seed, "", L, D), strict=True)
+    x = W.normal(seed, "x", (B, N, D))
+    dy = W.normal(seed, "dy", (B, N, D))
+    y, dx, grads = run_fwd_bwd(model, x, dy)
+    y16, dx16, g16 = run_fwd_bwd(model, x, dy, autocast_bf16=True)
+    save("transformer_layer_b.pt", {
+        "cfg": {"n_layers": L, "n_heads": H, "n_embd": D, "seq": N, "batch": B, "seed": seed, "causal": False},
+        "y": summarize(y), "dx": summarize(dx), "grads": {k: summarize(v) for k, v in grads.items()},
+        "y_row0": y[0, 0].clone(), "dx_row0": dx[0, 0].clone(),
+        "ref_bf16_floor": {"y": rel_l2(y16, y), "dx": rel_l2(dx16, dx),
+                           "grads": {k: rel_l2(g16[k], grads[k]) for k in grads}},
+    })
+
+
+def gen_classifier_fixture(TV, name, image_size, preset, num_classes, batch, seed, full_grads=False):
+    cfg = TV.ViTConfig(image_size, 3, 16, preset, 1, 0.0)
+    model = TV.ViTClassifier(cfg, num_classes=num_classes)
+    tc = cfg.trans_config
+    sd = W.classifier_state(seed, 3, 16, cfg.n_patches, 1, tc.n_layers, tc.n_embd, num_classes)
+    model.load_state_dict(sd, strict=True)
+    images = W.normal(seed, "images", (batch, 3, image_size, image_size))
+    labels = W.randint(seed, "labels", (batch,), num_classes)
+    loss_fn = torch.nn.CrossEntropyLoss()
+
+    def run(autocast_bf16):
+        model.zero_grad(set_to_none=True)
+        if autocast_bf16:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                logits = model(images)
+                loss = loss_fn(logits, labels)
+        else:
+            logits = model(images)
+            loss = loss_fn(logits, labels)
+        loss.backward()
+        return logits.detach().float(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    logits, loss, grads = run(False)
+    l16, loss16, g16 = run(True)
+    obj = {
+        "cfg": {"image_size": image_size, "preset": preset, "num_classes": num_classes, "batch": batch,
+                "seed": seed, "patch": 16, "extra_tokens": 1, "n_layers": tc.n_layers, "n_heads": tc.n_heads,
+                "n_embd": tc.n_embd, "n_patches": cfg.n_patches},
+        "n_params": sum(p.numel() for p in model.parameters()),
+        "state_keys": sorted(model.state_dict().keys()),
+        "state_shapes": {k: list(v.shape) for k, v in model.state_dict().items()},
+        "logits": logits, "loss": loss,
+        "grads": {k: summarize(v) for k, v in grads.items()},
+        "ref_bf16_floor": {"logits": rel_l2(l16, logits), "loss_abs": abs(loss16 - loss),
+                           "grads": {k: rel_l2(g16[k], grads[k]) for k in grads}},
+    }
+    if full_grads:
+        obj["full_grads"] = {k: grads[k] for k in ("head.weight", "head.bias", "vit.extra_emb.weight",
+                                                     "vit.pos_emb.weight", "vit.patch_proj.bias")}
+    save(name, obj)
+
+
+def gen_lr_fixture(RU):
+    base, warm, train, min_lr, steps = 1e-3, 10, 50, 1e-4, 70
+    p = torch.nn.Parameter(torch.zeros(1))
+    optim = torch.optim.AdamW([p], lr=base)
+    sched = RU.get_lr_scheduler(optim, warm, train, min_lr)
+    trace = []
+    for _ in range(steps):
+        trace.append(optim.param_groups[0]["lr"])
+        optim.step()
+        sched.step()
+    save("lr_schedule.pt", {"base_lr": base, "warmup_steps": warm, "train_steps": train, "min_lr": min_lr,
+                            "lrs": torch.tensor(trace, dtype=torch.float64)})
+
+
+def gen_train_steps_fixture(TV, RU):
+    """Config 1 plumbing: k full optimiser steps of the reference's loop body
+    (train_vit.py:99-107, fp32, no scaler) on a fixed batch; pins the training-step glue."""
+    seed, batch, num_classes, steps = 21, 16, 10, 4
+    cfg = TV.ViTConfig(32, 3, 16, "S", 1, 0.0)
+    model = TV.ViTClassifier(cfg, num_classes=num_classes)
+    tc = cfg.trans_config
+    model.load_state_dict(W.classifier_state(seed, 3, 16, cfg.n_patches, 1, tc.n_layers, tc.n_embd, num_classes))
+    images = W.normal(seed, "images", (batch, 3, 32, 32))
+    labels = W.randint(seed, "labels", (batch,), num_classes)
+    optim = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+    sched = RU.get_lr_scheduler(optim, 2, 100, 1e-4)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    losses = []
+    for _ in range(steps):
+        optim.zero_grad()
+        loss = loss_fn(model(images), labels)
+        loss.backward()
+        optim.step()
+        sched.step()
+        losses.append(float(loss))
+    save("train_steps_s32.pt", {"cfg": {"seed": seed, "batch": batch, "num_classes": num_classes, "steps": steps,
+                                        "lr": 1e-3, "weight_decay": 1e-2, "warmup": 2, "train_steps": 100, "min_lr": 1e-4},
+                                "losses": torch.tensor(losses, dtype=torch.float64),
+                                "final_head_bias": model.head.bias.detach().clone()})
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    RT, TV, RU = import_reference()
+    gen_transformer_fixtures(RT)
+    gen_classifier_fixture(TV, "vit_s32.pt", 32, "S", 10, 64, seed=13, full_grads=True)   # BASELINE config 1
+    gen_classifier_fixture(TV, "vit_b224.pt", 224, "B", 1000, 2, seed=14)                 # BASELINE config 2 shape
+    gen_lr_fixture(RU)
+    gen_train_steps_fixture(TV, RU)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,246 @@
+"""CPU oracle for the ViT training hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a functional, fp32, CPU restatement of the reference's algorithm for the hot
+path.  It is NOT part of the product: only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it, and there only
+as the checker.  The product path (`vit-is-all-you-need_amd/`) never imports it and fails
+loudly when the HIP library is missing.
+
+Parity status: PINNED.  `oracle/gen_golden.py` imports the reference's own modules from
+/root/reference in the build container (`transformer.py` as-is; the model classes of
+`train_vit.py`) and writes golden input/output vectors to `tests/golden/`;
+`tests/test_oracle.py` checks every function below against them (fp32, ~1e-6).
+
+All functions take plain tensors and a `state_dict`-style mapping that uses the reference's
+parameter names, so the checkpoint-key contract is exercised too.
+Everything is written with explicit matmul/softmax arithmetic (no nn.Module, no SDPA, no
+F.layer_norm) so that it is an independent statement of the maths.
+
+`lowp=True` turns on an emulation of the reference's autocast dtype flow with bf16 as the
+low-precision type (SURVEY.md section 5 "mixed precision": LayerNorm and the residual stream
+in fp32; Linear / attention / GELU inputs and outputs rounded to bf16, fp32 accumulation;
+gradients of bf16 tensors rounded to bf16).  That is the arithmetic the HIP kernels implement,
+so kernel-vs-oracle(lowp) is the tight check and oracle(lowp)-vs-oracle(fp32) is the measured
+precision floor of bf16 itself.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+LN_EPS = 1e-5  # F.layer_norm default eps; reference transformer.py:43-44 passes none
+
+
+# --------------------------------------------------------------------------------------
+# rounding helper for the lowp emulation
+# --------------------------------------------------------------------------------------
+class _RoundBF16(torch.autograd.Function):
+    """x -> bf16 -> fp32 in forward; the incoming gradient is rounded the same way
+    (under autocast the gradient of a bf16 tensor is itself a bf16 tensor)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _r(x: torch.Tensor, lowp: bool) -> torch.Tensor:
+    return _RoundBF16.apply(x) if lowp else x
+
+
+# --------------------------------------------------------------------------------------
+# configs (reference transformer.py:5-14, 56-59; train_vit.py:16-28)
+# --------------------------------------------------------------------------------------
+PRESETS = {"S": (6, 8, 512), "B": (12, 12, 768), "L": (24, 16, 1024)}  # transformer.py:56-58
+
+
+@dataclass
+class OracleViTConfig:
+    image_size: int
+    in_channels: int
+    patch_size: int
+    n_layers: int
+    n_heads: int
+    n_embd: int
+    extra_tokens: int
+    n_patches: int | None = None  # callers may override (train_titok.py:32)
+
+    def __post_init__(self):
+        if self.n_patches is None:
+            self.n_patches = (self.image_size // self.patch_size) ** 2  # train_vit.py:26
+
+    @property
+    def seq_len(self):
+        return self.n_patches + self.extra_tokens  # train_vit.py:28 block_size
+
+    @classmethod
+    def preset(cls, image_size, in_channels, patch_size, transformer, extra_tokens):
+        L, H, D = PRESETS[transformer]
+        return cls(image_size, in_channels, patch_size, L, H, D, extra_tokens)
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+def layer_norm(x: torch.Tensor) -> torch.Tensor:
+    """Non-affine LayerNorm over the last dim, biased variance, eps 1e-5.
+    Reference: transformer.py:43-44 `F.layer_norm(x, (self.n_embd,))`."""
+    mu = x.mean(dim=-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=-1, keepdim=True)
+    return xc * torch.rsqrt(var + LN_EPS)
+
+
+def linear(x, w, b, lowp=False):
+    """y = x @ w.T + b with PyTorch [out,in] weights.  Reference call sites
+    transformer.py:21,37,39 (nn.Linear).  lowp: operands and result rounded to bf16."""
+    y = _r(x, lowp) @ _r(w, lowp).t()
+    if b is not None:
+        y = y + _r(b, lowp)
+    return _r(y, lowp)
+
+
+def gelu_erf(x, lowp=False):
+    """Exact (erf) GELU; reference transformer.py:38 `nn.GELU()` (approximate='none')."""
+    return _r(0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0)))), lowp)
+
+
+def split_qkv(qkv: torch.Tensor, n_heads: int):
+    """[B,N,3D] -> q,k,v each [B,H,N,dh].  Output-channel order is (qkv, head, dh):
+    reference transformer.py:27 `rearrange(..., "b n (qkv h d) -> qkv b h n d")`."""
+    B, N, D3 = qkv.shape
+    dh = D3 // 3 // n_heads
+    t = qkv.reshape(B, N, 3, n_heads, dh).permute(2, 0, 3, 1, 4)
+    return t[0], t[1], t[2]
+
+
+def sdpa(q, k, v, causal=False, lowp=False):
+    """softmax(q k^T / sqrt(dh) + mask) v, mask = -inf strictly above the diagonal when
+    causal.  Reference transformer.py:22-25,28 (F.scaled_dot_product_attention with the
+    default scale and the additive mask buffer).  Dropout is 0 on every measured config."""
+    dh = q.shape[-1]
+    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    if causal:
+        n = q.shape[-2]
+        mask = torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
+        s = s.masked_fill(mask, float("-inf"))
+    s = s - s.amax(dim=-1, keepdim=True)
+    e = torch.exp(s)
+    denom = e.sum(dim=-1, keepdim=True)
+    if lowp:
+        # the kernels feed exp(s - max) to the matrix cores in bf16 and normalise afterwards
+        # with the fp32 row sum
+        return _r((_r(e, True) @ v) / denom, True)
+    return (e / denom) @ v
+
+
+def attention(x, sd, prefix, n_heads, causal=False, lowp=False):
+    """Reference transformer.py:26-29 (Attention.forward): fused QKV linear, split,
+    SDPA, merge heads `b h n d -> b n (h d)`.  There is NO output projection."""
+    qkv = linear(x, sd[prefix + "qkv.weight"], sd[prefix + "qkv.bias"], lowp)
+    q, k, v = split_qkv(qkv, n_heads)
+    o = sdpa(q, k, v, causal, lowp)  # [B,H,N,dh]
+    B, H, N, dh = o.shape
+    return o.permute(0, 2, 1, 3).reshape(B, N, H * dh)
+
+
+def mlp(x, sd, prefix, lowp=False):
+    """Reference transformer.py:36-41: Linear(D,4D) -> GELU -> Linear(4D,D) -> Dropout(0)."""
+    h = linear(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"], lowp)
+    h = gelu_erf(h, lowp)
+    return linear(h, sd[prefix + "2.weight"], sd[prefix + "2.bias"], lowp)
+
+
+def transformer_layer(x, sd, prefix, n_heads, causal=False, lowp=False):
+    """Reference transformer.py:42-45: x = x + attn(LN(x)); x = x + mlp(LN(x)).
+    The residual stream stays fp32 (fp32 + bf16 -> fp32 under autocast)."""
+    x = x + attention(layer_norm(x), sd, prefix + "multi_attn.", n_heads, causal, lowp)
+    x = x + mlp(layer_norm(x), sd, prefix + "mlp.", lowp)
+    return x
+
+
+def transformer(x, sd, prefix, n_layers, n_heads, causal=False, lowp=False):
+    """Reference transformer.py:52-54: sequential layers, no final norm."""
+    for i in range(n_layers):
+        x = transformer_layer(x, sd, f"{prefix}layers.{i}.", n_heads, causal, lowp)
+    return x
+
+
+def patchify(images: torch.Tensor, p: int) -> torch.Tensor:
+    """[B,C,Hh,Ww] -> [B, n_patches, C*p*p]; patches row-major over (h,w), patch vector in
+    (c,kh,kw) order — the contraction order of Conv2d(kernel=stride=p), train_vit.py:34,39-40."""
+    B, C, Hh, Ww = images.shape
+    gh, gw = Hh // p, Ww // p
+    t = images.reshape(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5)
+    return t.reshape(B, gh * gw, C * p * p)
+
+
+def vit_embed(images, sd, prefix, cfg: OracleViTConfig, lowp=False):
+    """Reference train_vit.py:38-44 (ViT.forward prologue): conv patchify, + pos_emb on the
+    patch tokens only, learned extra tokens PREPENDED (indices 0..extra-1)."""
+    D = cfg.n_embd
+    w = sd[prefix + "patch_proj.weight"].reshape(D, -1)  # [D, C*p*p]
+    tok = linear(patchify(images, cfg.patch_size), w, sd[prefix + "patch_proj.bias"], lowp)
+    tok = tok + sd[prefix + "pos_emb.weight"][: cfg.n_patches]
+    extra = sd[prefix + "extra_emb.weight"].unsqueeze(0).expand(images.shape[0], -1, -1)
+    return torch.cat([extra, tok], dim=1)
+
+
+def vit(images, sd, prefix, cfg: OracleViTConfig, lowp=False):
+    """Reference train_vit.py:38-45 (ViT.forward)."""
+    x = vit_embed(images, sd, prefix, cfg, lowp)
+    return transformer(x, sd, prefix + "transformer.", cfg.n_layers, cfg.n_heads, False, lowp)
+
+
+def vit_classifier(images, sd, cfg: OracleViTConfig, lowp=False):
+    """Reference train_vit.py:53: head(vit(x)[:, 0])."""
+    feat = vit(images, sd, "vit.", cfg, lowp)[:, 0]
+    return linear(feat, sd["head.weight"], sd["head.bias"], lowp)
+
+
+def cross_entropy(logits, labels):
+    """Mean softmax cross-entropy; reference train_vit.py:81,102 (nn.CrossEntropyLoss)."""
+    z = logits.float()
+    lse = torch.logsumexp(z, dim=-1)
+    return (lse - z.gather(1, labels[:, None]).squeeze(1)).mean()
+
+
+# --------------------------------------------------------------------------------------
+# LR schedule (reference utils.py:5-9), closed form
+# --------------------------------------------------------------------------------------
+def lr_at(step: int, base_lr: float, warmup_steps: int, train_steps: int, min_lr: float) -> float:
+    """Learning rate in effect for optimiser step number `step` (0-based) under the
+    reference's SequentialLR[warmup LambdaLR, CosineAnnealingLR(T_max=train_steps), const]
+    with milestones [warmup_steps, train_steps].  Quirks reproduced on purpose (SURVEY.md
+    section 5): the cosine starts counting at the warmup milestone, so only
+    (train_steps - warmup_steps)/train_steps of it elapses, and at `train_steps` the rate
+    jumps back to base_lr."""
+    if step < warmup_steps:
+        return base_lr * min(1.0, step / warmup_steps)
+    if step < train_steps:
+        t = step - warmup_steps
+        return min_lr + (base_lr - min_lr) * (1 + math.cos(math.pi * t / train_steps)) / 2
+    return base_lr
+
+
+# --------------------------------------------------------------------------------------
+# convenience: forward + backward returning gradients keyed like the state_dict
+# --------------------------------------------------------------------------------------
+def classifier_loss_and_grads(images, labels, sd, cfg: OracleViTConfig, lowp=False):
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    logits = vit_classifier(images, leaves, cfg, lowp)
+    loss = cross_entropy(logits, labels)
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    return logits.detach(), loss.detach(), dict(zip(leaves.keys(), grads))
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    """||a-b|| / ||b|| in fp64 — the comparison metric used by every parity test."""
+    a = a.detach().double().flatten()
+    b = b.detach().double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))

@@ -1,0 +1,79 @@
+"""Deterministic, torch-RNG-free parameter / input generator.  TEST INFRASTRUCTURE ONLY.
+
+Golden fixtures store seeds instead of weights: both the fixture generator (which feeds the
+values to the real reference in the build container) and the tests on the GPU box (where the
+reference does not exist) rebuild bit-identical tensors from numpy's PCG64, whose stream is
+stable across platforms and numpy versions.
+
+Distributions follow the reference's default initialisers:
+Linear / Conv2d weight and bias ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)); Embedding ~ N(0,1).
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def uniform(seed, name, shape, bound) -> torch.Tensor:
+    a = _rng(seed, name).uniform(-bound, bound, size=shape).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+def normal(seed, name, shape, std=1.0) -> torch.Tensor:
+    a = (_rng(seed, name).standard_normal(size=shape) * std).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+def randint(seed, name, shape, high) -> torch.Tensor:
+    return torch.from_numpy(_rng(seed, name).integers(0, high, size=shape, dtype=np.int64))
+
+
+def transformer_state(seed, prefix, n_layers, n_embd, causal_block=None) -> dict:
+    """Parameters of reference transformer.Transformer under `prefix` (keys as in
+    transformer.py:21,36-41,51)."""
+    D = n_embd
+    sd = {}
+    for i in range(n_layers):
+        p = f"{prefix}layers.{i}."
+        b = 1.0 / np.sqrt(D)
+        sd[p + "multi_attn.qkv.weight"] = uniform(seed, p + "qkv.w", (3 * D, D), b)
+        sd[p + "multi_attn.qkv.bias"] = uniform(seed, p + "qkv.b", (3 * D,), b)
+        if causal_block is not None:  # persistent buffer, transformer.py:22-25
+            m = torch.triu(torch.ones(causal_block, causal_block), diagonal=1)
+            sd[p + "multi_attn.mask"] = m.masked_fill(m == 1, float("-inf"))
+        sd[p + "mlp.0.weight"] = uniform(seed, p + "fc1.w", (4 * D, D), b)
+        sd[p + "mlp.0.bias"] = uniform(seed, p + "fc1.b", (4 * D,), b)
+        b2 = 1.0 / np.sqrt(4 * D)
+        sd[p + "mlp.2.weight"] = uniform(seed, p + "fc2.w", (D, 4 * D), b2)
+        sd[p + "mlp.2.bias"] = uniform(seed, p + "fc2.b", (D,), b2)
+    return sd
+
+
+def vit_state(seed, prefix, in_channels, patch, n_patches, extra, n_layers, n_embd) -> dict:
+    """Parameters of reference train_vit.ViT under `prefix` (train_vit.py:34-37)."""
+    D = n_embd
+    fan_in = in_channels * patch * patch
+    b = 1.0 / np.sqrt(fan_in)
+    sd = {
+        prefix + "patch_proj.weight": uniform(seed, prefix + "pp.w", (D, in_channels, patch, patch), b),
+        prefix + "patch_proj.bias": uniform(seed, prefix + "pp.b", (D,), b),
+        prefix + "pos_emb.weight": normal(seed, prefix + "pos", (n_patches, D)),
+        prefix + "extra_emb.weight": normal(seed, prefix + "extra", (extra, D)),
+    }
+    sd.update(transformer_state(seed, prefix + "transformer.", n_layers, D))
+    return sd
+
+
+def classifier_state(seed, in_channels, patch, n_patches, extra, n_layers, n_embd, num_classes) -> dict:
+    """Parameters of reference train_vit.ViTClassifier (train_vit.py:50-51)."""
+    sd = vit_state(seed, "vit.", in_channels, patch, n_patches, extra, n_layers, n_embd)
+    b = 1.0 / np.sqrt(n_embd)
+    sd["head.weight"] = uniform(seed, "head.w", (num_classes, n_embd), b)
+    sd["head.bias"] = uniform(seed, "head.b", (num_classes,), b)
+    return sd

@@ -1,0 +1,99 @@
+"""Pins the CPU oracle (oracle/vit_oracle.py) to the golden vectors that
+oracle/gen_golden.py produced from the real reference (fp32, CPU)."""
+import torch
+
+import vit_oracle as O
+import weights as W
+from conftest import load_golden
+
+STRIDE = 997
+
+
+def _sample(t):
+    return t.detach().flatten()[::STRIDE].float()
+
+
+def _run_transformer(g, lowp=False):
+    c = g["cfg"]
+    sd = W.transformer_state(c["seed"], "", c["n_layers"], c["n_embd"], causal_block=c["seq"] if c["causal"] else None)
+    x = W.normal(c["seed"], "x", (c["batch"], c["seq"], c["n_embd"])).requires_grad_(True)
+    dy = W.normal(c["seed"], "dy", (c["batch"], c["seq"], c["n_embd"]))
+    leaves = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "mask" not in k) for k, v in sd.items()}
+    y = O.transformer(x, leaves, "", c["n_layers"], c["n_heads"], c["causal"], lowp)
+    names = [k for k in leaves if "mask" not in k]
+    grads = torch.autograd.grad((y * dy).sum(), [x] + [leaves[k] for k in names])
+    return y.detach(), grads[0], dict(zip(names, grads[1:])), sd
+
+
+def test_transformer_tiny_matches_reference():
+    for name in ("transformer_tiny.pt", "transformer_tiny_causal.pt"):
+        g = load_golden(name)
+        y, dx, grads, sd = _run_transformer(g)
+        assert sorted(sd.keys()) == g["state_keys"]  # checkpoint-key contract incl. causal mask buffer
+        assert O.rel_l2(y, g["y"]) < 2e-6
+        assert O.rel_l2(dx, g["dx"]) < 2e-6
+        for k, ref in g["grads"].items():
+            assert O.rel_l2(grads[k], ref) < 5e-6, k
+
+
+def test_transformer_layer_b_matches_reference():
+    g = load_golden("transformer_layer_b.pt")
+    y, dx, grads, _ = _run_transformer(g)
+    assert O.rel_l2(_sample(y), g["y"]["sample"]) < 2e-6
+    assert abs(float(y.double().norm()) - g["y"]["norm"]) / g["y"]["norm"] < 1e-6
+    assert O.rel_l2(y[0, 0], g["y_row0"]) < 2e-6
+    assert O.rel_l2(_sample(dx), g["dx"]["sample"]) < 2e-6
+    for k, ref in g["grads"].items():
+        assert O.rel_l2(_sample(grads[k]), ref["sample"]) < 1e-5, k
+        assert abs(float(grads[k].double().norm()) - ref["norm"]) / ref["norm"] < 1e-5, k
+
+
+def test_lowp_emulation_is_within_the_references_own_bf16_floor():
+    """oracle(lowp) models the autocast dtype flow; its distance from fp32 must be of the
+    same size as the reference's own CPU-autocast distance (recorded in the fixture)."""
+    g = load_golden("transformer_tiny.pt")
+    y, dx, grads, _ = _run_transformer(g, lowp=True)
+    floor = g["ref_bf16_floor"]
+    assert O.rel_l2(y, g["y"]) < 2.0 * floor["y"] + 1e-3
+    assert O.rel_l2(dx, g["dx"]) < 2.0 * floor["dx"] + 1e-3
+
+
+def _run_classifier(g, lowp=False):
+    c = g["cfg"]
+    cfg = O.OracleViTConfig(c["image_size"], 3, c["patch"], c["n_layers"], c["n_heads"], c["n_embd"], c["extra_tokens"])
+    sd = W.classifier_state(c["seed"], 3, c["patch"], c["n_patches"], c["extra_tokens"], c["n_layers"], c["n_embd"], c["num_classes"])
+    images = W.normal(c["seed"], "images", (c["batch"], 3, c["image_size"], c["image_size"]))
+    labels = W.randint(c["seed"], "labels", (c["batch"],), c["num_classes"])
+    return O.classifier_loss_and_grads(images, labels, sd, cfg, lowp), sd
+
+
+def _check_classifier(name, tol):
+    g = load_golden(name)
+    (logits, loss, grads), sd = _run_classifier(g)
+    assert sorted(sd.keys()) == g["state_keys"]
+    assert {k: list(v.shape) for k, v in sd.items()} == g["state_shapes"]
+    assert sum(v.numel() for v in sd.values()) == g["n_params"]
+    assert O.rel_l2(logits, g["logits"]) < tol
+    assert abs(float(loss) - g["loss"]) < tol * max(1.0, abs(g["loss"]))
+    for k, ref in g["grads"].items():
+        assert O.rel_l2(_sample(grads[k]), ref["sample"]) < 20 * tol, k
+        assert abs(float(grads[k].double().norm()) - ref["norm"]) / max(ref["norm"], 1e-30) < 20 * tol, k
+    for k, ref in g.get("full_grads", {}).items():
+        assert O.rel_l2(grads[k], ref) < 20 * tol, k
+
+
+def test_vit_s32_classifier_matches_reference():   # BASELINE config 1 shape (S/16, 32x32, 10 classes, batch 64)
+    _check_classifier("vit_s32.pt", 3e-6)
+
+
+def test_vit_b224_classifier_matches_reference():  # BASELINE config 2 shape at batch 2
+    g = load_golden("vit_b224.pt")
+    assert g["n_params"] == 79_441_384 and len(g["state_keys"]) == 78
+    _check_classifier("vit_b224.pt", 5e-6)
+
+
+def test_lr_schedule_matches_reference_trace():
+    g = load_golden("lr_schedule.pt")
+    for s, lr in enumerate(g["lrs"].tolist()):
+        mine = O.lr_at(s, g["base_lr"], g["warmup_steps"], g["train_steps"], g["min_lr"])
+        assert abs(mine - lr) < 1e-12, (s, mine, lr)
