@@ -1,0 +1,183 @@
+"""Headline benchmark: images/sec of ViT-B/16 224x224 bf16 forward + loss + backward
+(BASELINE.json metric / configs[1]) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of 256 synthetic images per GPU: per-step bf16
+weight cast, patch embed, 12 transformer layers, head, cross-entropy, full backward to every
+parameter gradient and (N > 1) the bucketed RCCL gradient all-reduce, overlapped with backward.
+Inputs are resident in HBM before timing.  The optimiser step is outside the metric.
+Weak scaling: 256 images per GPU at every N.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
+
+GFLOP_PER_IMAGE = 96.786        # SURVEY.md section 8d / BASELINE.md section 3 (fwd 32.339 + bwd 64.447)
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PER_GPU_BATCH = 256
+
+
+def kernel_roofline(dev):
+    """Live HIP-event timing of the dominant kernel (the NT MFMA GEMM: every forward Linear and
+    every input-gradient GEMM, ~2/3 of the step's FLOPs) at each of the six shapes one step launches
+    it with.  achieved = algorithmic FLOPs (2*M*N*K per launch) / average launch duration, weighted
+    over the launches of one step."""
+    from vitamd import ops
+    M, D = PER_GPU_BATCH * 197, 768
+    g = torch.Generator(device="cpu").manual_seed(1)
+
+    def rb(*s, scale=1.0):
+        return (torch.randn(*s, generator=g) * scale).to(dev, torch.bfloat16)
+
+    x1, x3, x4 = rb(M, D), rb(M, 3 * D), rb(M, 4 * D)
+    wqkv, w1, w2 = rb(3 * D, D, scale=0.03), rb(4 * D, D, scale=0.03), rb(D, 4 * D, scale=0.03)
+    wqkv_t, w1_t, w2_t = rb(D, 3 * D, scale=0.03), rb(D, 4 * D, scale=0.03), rb(4 * D, D, scale=0.03)
+    b3, b4, b1 = torch.randn(3 * D, device=dev), torch.randn(4 * D, device=dev), torch.randn(D, device=dev)
+    res = torch.randn(M, D, device=dev)
+    cs = torch.zeros(4 * D, device=dev)
+    calls = [
+        ("qkv", lambda: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3), 2.0 * M * D * 3 * D),
+        ("fc1+gelu", lambda: ops.gemm_nt(x1, w1, ops.EPI_GELU, bias=b4), 2.0 * M * D * 4 * D),
+        ("fc2+resid", lambda: ops.gemm_nt(x4, w2, ops.EPI_RESID_F32, bias=b1, aux=res), 2.0 * M * D * 4 * D),
+        ("dgrad_fc2", lambda: ops.gemm_nt(x1, w2_t, ops.EPI_DGELU, aux=x4, colsum=cs), 2.0 * M * D * 4 * D),
+        ("dgrad_fc1", lambda: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 4 * D),
+        ("dgrad_qkv", lambda: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 3 * D),
+    ]
+    tot_flops, tot_ms, detail = 0.0, 0.0, {}
+    for name, fn, flops in calls:
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()                      # our kernels launch on torch's current stream: events see them
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / 10
+        detail[name] = round(flops / ms / 1e9, 1)
+        tot_flops += flops
+        tot_ms += ms
+    achieved = tot_flops / tot_ms / 1e9
+    return {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256> (6 shapes/layer)", "achieved": round(achieved, 1),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "per_shape_tflops": detail}
+
+
+def cpu_baseline():
+    """The CPU oracle (fp32 restatement of the reference, oracle/vit_oracle.py) timed on this
+    host's cores on a bounded sample: 2 forward+backward iterations of batch 16 after one warm-up."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vit_oracle as O
+    import weights as W
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cfg = O.OracleViTConfig.preset(224, 3, 16, "B", 1)
+    sd = W.classifier_state(0, 3, 16, cfg.n_patches, 1, cfg.n_layers, cfg.n_embd, 1000)
+    bs, iters = 16, 2
+    images = W.normal(0, "images", (bs, 3, 224, 224))
+    labels = W.randint(0, "labels", (bs,), 1000)
+    O.classifier_loss_and_grads(images[:4], labels[:4], sd, cfg)
+    t0 = time.time()
+    for _ in range(iters):
+        O.classifier_loss_and_grads(images, labels, sd, cfg)
+    dt = time.time() - t0
+    return {"value": round(bs * iters / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{iters} x (batch {bs} ViT-B/16 224 fp32 forward+loss+backward), CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import train_vit as TV
+    from vitamd.ddp import DataParallel
+    from vitamd.functions import WEIGHTS
+
+    torch.manual_seed(0)
+    model = TV.ViTClassifier(TV.ViTConfig(224, 3, 16, "B", 1, 0.0), num_classes=1000).to(dev)
+    net = DataParallel(model) if world > 1 else model
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)   # each rank owns its shard of the global batch
+    images = torch.randn(PER_GPU_BATCH, 3, 224, 224, generator=g).to(dev)
+    labels = torch.randint(0, 1000, (PER_GPU_BATCH,), generator=g).to(dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        WEIGHTS.clear()                      # weights are re-cast to bf16 every step, as in training
+        loss = torch.nn.functional.cross_entropy(net(images), labels)
+        loss.backward()
+        if world > 1:
+            net.finish()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = PER_GPU_BATCH * world / (ms / 1e3)
+        out = {
+            "metric": "images/sec ViT-B/16 224px bf16 fwd+bwd", "value": round(value, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-B/16 224x224 bf16 forward+loss+backward, batch 256 per GPU (BASELINE configs[1]; "
+                                   "configs[2] at 8 GPUs), random-init weights, 197 tokens, 79.44 M params",
+                       "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}"},
+            "model_flops_frac_of_peak": round(value / world * GFLOP_PER_IMAGE / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(loss_val, 4),
+        }
+        if not args.no_roofline:
+            out["roofline"] = kernel_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+/* vitamd.h — C ABI of libvitamd.so, the MI355X (gfx950) kernels behind the ViT training hot path.
+ *
+ * The reference (SnakeOnex/vit-is-all-you-need) has no FFI layer: its hot path is a handful of
+ * PyTorch ATen calls made from transformer.py and train_vit.py.  Each entry point below replaces
+ * one (or a fused group) of those call sites; the citation after "replaces" is the reference
+ * file:line.  A maintainer binds them with ctypes; the build's own
+ * `vit-is-all-you-need_amd/vitamd/lib.py` is exactly that binding.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM), row-major, 16-byte aligned.  "bf16" buffers are
+ *     passed as void*; fp32 buffers as float*.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls only enqueue work:
+ *     no allocation, no synchronisation, safe under HIP-graph capture.
+ *   - Every function returns VITAMD_OK (0) or a VITAMD_ERR_* code and launches nothing on error.
+ *   - The caller owns all memory.  Kernels never allocate.
+ */
+#ifndef VITAMD_H
+#define VITAMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITAMD_OK 0
+#define VITAMD_ERR_SHAPE 1   /* unsupported / inconsistent dimensions */
+#define VITAMD_ERR_ARG 2     /* missing pointer or bad enum */
+#define VITAMD_ERR_LAUNCH 3  /* HIP reported a launch error */
+
+/* ABI version of this header (bumped on any signature change). */
+int vitamd_abi_version(void);
+
+/* ---- Linear layers: C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation (MFMA) ------
+ * epilogue selectors (argument `epi`):                                                          */
+#define VITAMD_EPI_BIAS_BF16 0 /* out bf16 = bf16(acc + bias)                      replaces transformer.py:21,27 (qkv Linear) */
+#define VITAMD_EPI_GELU 1      /* out bf16 = pre-activation, out2 bf16 = erf-GELU  replaces transformer.py:37-38 (Linear + nn.GELU) */
+#define VITAMD_EPI_RESID_F32 2 /* out f32 = aux_f32 + bf16(acc + bias)             replaces transformer.py:39-40,44 (Linear + Dropout(0) + residual add) */
+#define VITAMD_EPI_DGELU 3     /* out bf16 = bf16(acc) * gelu'(aux_bf16); colsum += column sums   (backward of transformer.py:38-39) */
+#define VITAMD_EPI_PATCH_F32 4 /* out f32[b*seq+extra+p] = bf16(acc+bias) + aux_f32[p]  replaces train_vit.py:39-41 (Conv2d patchify + rearrange + pos_emb) */
+#define VITAMD_EPI_F32 5       /* out f32 = acc */
+
+/* Requirements: K % 64 == 0, N % 4 == 0, ldo % 4 == 0.  bias may be NULL.  `tile` 0 = auto.
+ * Forward of nn.Linear (x W^T + b): A = x, B = W.  Input gradient (dy W): A = dy, B = W^T. */
+int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
+                        float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
+                        int tile, void* stream);
+
+/* Weight gradient: out[P,Q] (fp32) += sum_r L[r,p] * Rm[r,q]   (dW = dY^T X).  Accumulates with
+ * fp32 atomics, so `out` must hold the running gradient (zeros for a fresh one).
+ * replaces the autograd backward of transformer.py:21,37,39 and train_vit.py:34.
+ * Requirements: ldl % 8 == 0, ldr % 8 == 0.  `splits` 0 = auto. */
+int vitamd_gemm_tn_bf16(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
+                        int splits, void* stream);
+
+/* ---- LayerNorm (no affine, eps as given) on the fp32 residual stream -------------------------
+ * forward: x = x_in (+ addend_bf16 -> also written to x_out); y = bf16(LN(x)); mean/rstd saved.
+ * replaces transformer.py:43-44 `F.layer_norm(x, (n_embd,))` and the residual add of :43. */
+int vitamd_layernorm_fwd(const float* x_in, const void* addend_bf16, float* x_out, void* y_bf16, float* mean,
+                         float* rstd, int M, int D, float eps, void* stream);
+/* backward: g_out = (g_res ? g_res : 0) + LN'(dy_bf16); optional bf16 copy of g_out and its column sums. */
+int vitamd_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                         const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D, void* stream);
+
+/* ---- Attention on the packed fused-QKV layout ------------------------------------------------
+ * qkv bf16 [B,N,3,H,64] (output-channel order (qkv, head, dh) of transformer.py:27), o bf16 [B,N,H*64],
+ * lse2 fp32 [B,H,N].  head_dim must be 64, N <= 512.  causal != 0 applies the strictly-upper -inf
+ * mask of transformer.py:22-25.   replaces transformer.py:27-29 (rearrange + SDPA + rearrange). */
+int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal,
+                         void* stream);
+/* dqkv bf16 [B,N,3,H,64]; delta fp32 [B,H,N] is scratch written by the call. */
+int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, const void* d_o, void* dqkv,
+                         float* delta, int B, int N, int H, int head_dim, int causal, void* stream);
+
+/* ---- helpers around the GEMMs ---------------------------------------------------------------- */
+/* fp32 -> bf16 (autocast's per-step weight / activation cast, train_vit.py:100). */
+int vitamd_cast_f32_bf16(const float* in, void* out_bf16, long n, void* stream);
+/* W fp32 [N,K] -> bf16 [N,K] (wb, may be NULL) and transposed bf16 [K,N] (wbt, may be NULL). */
+int vitamd_cast_transpose_weight(const float* w, void* wb, void* wbt, int N, int K, void* stream);
+/* images fp32 [B,C,H,W] -> patches bf16 [B*(H/p)*(W/p), C*p*p], vector order (c,kh,kw): the
+ * contraction order of Conv2d(kernel=stride=p), train_vit.py:34,39. */
+int vitamd_im2col_bf16(const float* img, void* out_bf16, int B, int C, int H, int W, int p, void* stream);
+/* out[n] += sum_m X[m,n]  (bias gradients). */
+int vitamd_colsum_bf16(const void* x_bf16, float* out, int M, int N, int ld, void* stream);
+/* Backward of the token assembly train_vit.py:41-44: g fp32 [B,seq,D] -> dpos [seq-extra,D],
+ * dextra [extra,D], compact bf16 patch rows dyp [B*(seq-extra),D], dbias[D] += their column sums. */
+int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16, float* dbias, int B, int seq,
+                     int extra, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITAMD_H */

@@ -67,9 +67,15 @@ def sample(t: torch.Tensor) -> torch.Tensor:
     return t.detach().flatten()[::SAMPLE_STRIDE].clone().float()
 
 
+SMALL = 1 << 16  # tensors up to this many elements are stored in full
+
+
 def summarize(t: torch.Tensor) -> dict:
     t = t.detach().float()
-    return {"norm": float(t.double().norm()), "sample": sample(t), "shape": list(t.shape)}
+    d = {"norm": float(t.double().norm()), "sample": sample(t), "shape": list(t.shape)}
+    if t.numel() <= SMALL:
+        d["full"] = t.clone()
+    return d
 
 
 def save(name, obj):

@@ -1,0 +1,203 @@
+"""Per-kernel checks of libvitamd.so through the C ABI on a real MI355X.
+Integer-valued operands make the MFMA results exact, so fragment-layout mistakes show up as
+exact mismatches (asymmetric operands: a transposed result cannot pass)."""
+import math
+
+import pytest
+import torch
+
+import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def dev():
+    return torch.device("cuda")
+
+
+def ints(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float()
+
+
+def randn(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def r16(x):
+    return x.to(BF16).float()
+
+
+# ------------------------------------------------------------------------------------------ gemm_nt
+@pytest.mark.parametrize("M,N,K,tile", [(256, 256, 64, 256), (512, 768, 768, 256), (320, 1536, 512, 128), (111, 128, 128, 128),
+                                        (1000, 2304, 768, 256), (197 * 4, 768, 3072, 0), (64, 64, 64, 0), (300, 1024, 192, 256)])
+def test_gemm_nt_exact_integers(hip, M, N, K, tile):
+    from vitamd import ops
+    a = ints((M, K), -3, 3, 1)
+    b = ints((N, K), -2, 2, 2)
+    ref = a @ b.t()
+    out = ops.gemm_nt(a.to(dev(), BF16), b.to(dev(), BF16), ops.EPI_F32, tile=tile)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_nt_epilogues(hip):
+    from vitamd import ops
+    M, N, K = 333, 512, 256
+    a, b = r16(randn((M, K), 3)), r16(randn((N, K), 4, 0.1))
+    bias = randn((N,), 5)
+    acc = a @ b.t()
+    ad, bd, biasd = a.to(dev(), BF16), b.to(dev(), BF16), bias.to(dev())
+    # bias -> bf16
+    y = ops.gemm_nt(ad, bd, ops.EPI_BIAS_BF16, bias=biasd).float().cpu()
+    ref = r16(acc + r16(bias))
+    assert O.rel_l2(y, ref) < 2e-3
+    # gelu (two outputs)
+    pre, act = ops.gemm_nt(ad, bd, ops.EPI_GELU, bias=biasd)
+    assert O.rel_l2(pre.float().cpu(), ref) < 2e-3
+    assert O.rel_l2(act.float().cpu(), r16(O.gelu_erf(pre.float().cpu()))) < 2e-3
+    # residual fp32
+    res = randn((M, N), 6)
+    y = ops.gemm_nt(ad, bd, ops.EPI_RESID_F32, bias=biasd, aux=res.to(dev())).cpu()
+    assert O.rel_l2(y, res + ref) < 1e-3
+    # dgelu + column sums
+    prez = r16(randn((M, N), 7))
+    cs = torch.zeros(N, device=dev())
+    y = ops.gemm_nt(ad, bd, ops.EPI_DGELU, aux=prez.to(dev(), BF16), colsum=cs).float().cpu()
+    x = prez.clone().requires_grad_(True)
+    O.gelu_erf(x).backward(r16(acc))
+    assert O.rel_l2(y, r16(x.grad)) < 3e-3
+    assert O.rel_l2(cs.cpu(), y.sum(0)) < 1e-4
+    # patch epilogue: row remap + pos add
+    n_p, extra = 9, 2
+    Bn = 37
+    a2 = r16(randn((Bn * n_p, K), 8))
+    pos = randn((n_p, N), 9)
+    out = torch.full((Bn * (n_p + extra), N), 7.0, device=dev())
+    ops.gemm_nt(a2.to(dev(), BF16), bd, ops.EPI_PATCH_F32, bias=biasd, aux=pos.to(dev()), out=out, n_patches=n_p, seq=n_p + extra, extra=extra)
+    got = out.cpu().view(Bn, n_p + extra, N)
+    want = r16(a2 @ b.t() + r16(bias)).view(Bn, n_p, N) + pos
+    assert torch.all(got[:, :extra] == 7.0)
+    assert O.rel_l2(got[:, extra:], want) < 1e-3
+
+
+def test_gemm_nt_rejects_bad_shapes(hip):
+    from vitamd import ops, lib
+    a = torch.zeros((64, 100), device=dev(), dtype=BF16)
+    b = torch.zeros((64, 100), device=dev(), dtype=BF16)
+    with pytest.raises(lib.VitamdError):
+        ops.gemm_nt(a, b, ops.EPI_F32)           # K % 64 != 0
+    with pytest.raises(lib.VitamdError):
+        ops.gemm_nt(a.cpu(), b, ops.EPI_F32)     # host tensor
+
+
+# ------------------------------------------------------------------------------------------ gemm_tn
+@pytest.mark.parametrize("R,P,Q,splits", [(64, 256, 256, 1), (128, 256, 256, 2), (1000, 512, 768, 0), (111, 128, 64, 0),
+                                          (197 * 8, 2304, 768, 0), (320, 1536, 512, 3), (70, 16, 512, 1), (4096, 768, 3072, 0)])
+def test_gemm_tn_exact_integers(hip, R, P, Q, splits):
+    from vitamd import ops
+    l = ints((R, P), -2, 2, 11)
+    r = ints((R, Q), -3, 3, 12)
+    init = ints((P, Q), -5, 5, 13)
+    ref = init + l.t() @ r
+    out = init.to(dev())
+    ops.gemm_tn(l.to(dev(), BF16), r.to(dev(), BF16), out, splits=splits)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------ layernorm
+@pytest.mark.parametrize("M,D", [(1, 768), (777, 768), (320, 512), (111, 128), (50, 1024), (33, 200)])
+def test_layernorm_fwd_bwd(hip, M, D):
+    from vitamd import ops
+    x = randn((M, D), 21, 2.0) + 0.5
+    add = r16(randn((M, D), 22))
+    xs, y, mean, rstd = ops.layernorm_fwd(x.to(dev()), addend=add.to(dev(), BF16))
+    xr = (x + add).requires_grad_(True)
+    yr = O.layer_norm(xr)
+    assert O.rel_l2(xs.cpu(), xr) < 1e-6
+    assert O.rel_l2(y.float().cpu(), r16(yr)) < 3e-3
+    assert O.rel_l2(mean.cpu(), xr.mean(-1)) < 1e-5
+    _, y2, _, _ = ops.layernorm_fwd(x.to(dev()))
+    assert O.rel_l2(y2.float().cpu(), r16(O.layer_norm(x))) < 3e-3
+    dy = r16(randn((M, D), 23))
+    gres = randn((M, D), 24)
+    cs = torch.zeros(D, device=dev())
+    g, gb = ops.layernorm_bwd(dy.to(dev(), BF16), xs, mean, rstd, g_res=gres.to(dev()), want_bf16=True, colsum=cs)
+    yr.backward(dy)
+    want = gres + xr.grad
+    assert O.rel_l2(g.cpu(), want) < 1e-5
+    assert torch.equal(gb.float().cpu(), r16(g.cpu()))
+    assert O.rel_l2(cs.cpu(), gb.float().cpu().sum(0)) < 1e-4
+    g2, none = ops.layernorm_bwd(dy.to(dev(), BF16), xs, mean, rstd)
+    assert none is None and O.rel_l2(g2.cpu(), xr.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, N, H, causal, d_o=None):
+    t = qkv.view(B, N, 3 * H * 64).clone().requires_grad_(True)
+    q, k, v = O.split_qkv(t, H)
+    o = O.sdpa(q, k, v, causal, lowp=True).permute(0, 2, 1, 3).reshape(B * N, H * 64)
+    if d_o is None:
+        return o.detach(), None
+    o.backward(d_o)
+    return o.detach(), t.grad.view(B * N, -1)
+
+
+@pytest.mark.parametrize("B,N,H,causal", [(2, 5, 2, False), (1, 32, 1, False), (3, 37, 2, True), (2, 197, 3, False),
+                                          (1, 288, 2, False), (2, 64, 2, True), (1, 197, 2, True), (1, 512, 1, False)])
+def test_attention_fwd_bwd(hip, B, N, H, causal):
+    from vitamd import ops
+    qkv = r16(randn((B * N, 3 * H * 64), 31 + N, 1.5))
+    d_o = r16(randn((B * N, H * 64), 32 + N))
+    o_ref, dqkv_ref = _attn_ref(qkv, B, N, H, causal, d_o)
+    qd = qkv.to(dev(), BF16)
+    o, lse = ops.attention_fwd(qd, B, N, H, causal)
+    assert O.rel_l2(o.float().cpu(), o_ref) < 6e-3
+    # log-sum-exp (log2 domain) against the definition
+    q, k, _ = O.split_qkv(qkv.view(B, N, -1), H)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
+    assert O.rel_l2(lse.cpu(), torch.logsumexp(s, -1) / math.log(2.0)) < 1e-4
+    dqkv = ops.attention_bwd(qd, o, lse, d_o.to(dev(), BF16), B, N, H, causal).float().cpu()
+    D = H * 64
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 1.2e-2, name
+
+
+def test_attention_softmax_spike(hip):
+    """A key that dominates late in the sequence forces the online-softmax rescale branch."""
+    from vitamd import ops
+    B, N, H = 1, 197, 1
+    qkv = r16(randn((B * N, 3 * 64), 77, 0.5))
+    qkv[150, 64:128] = r16(qkv[10, 0:64] * 40.0)  # key 150 aligned with query 10
+    o_ref, _ = _attn_ref(qkv, B, N, H, False)
+    o, _ = ops.attention_fwd(qkv.to(dev(), BF16), B, N, H, False)
+    assert O.rel_l2(o.float().cpu(), o_ref) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def test_cast_transpose_im2col_colsum_embed(hip):
+    from vitamd import ops
+    w = randn((1000, 768), 41)
+    wb, wbt = ops.cast_weight(w.to(dev()), True, True)
+    assert torch.equal(wb.float().cpu(), r16(w)) and torch.equal(wbt.float().cpu(), r16(w).t())
+    x = randn((100003,), 42)
+    assert torch.equal(ops.cast_bf16(x.to(dev())).float().cpu(), r16(x))
+    for (B, C, H, W, p) in ((3, 3, 32, 32, 16), (2, 3, 224, 224, 16), (2, 8, 5, 1, 1), (1, 3, 24, 36, 12)):
+        img = randn((B, C, H, W), 43)
+        assert torch.equal(ops.im2col(img.to(dev()), p).float().cpu(), r16(O.patchify(img, p)).reshape(-1, C * p * p))
+    m = r16(randn((5000, 770), 44))
+    assert O.rel_l2(ops.colsum(m.to(dev(), BF16)).cpu(), m.sum(0)) < 1e-5
+    B, seq, extra, D = 7, 11, 2, 256
+    g = randn((B * seq, D), 45)
+    dpos, dextra, dyp, dbias = ops.embed_bwd(g.to(dev()), B, seq, extra, D)
+    g3 = g.view(B, seq, D)
+    assert O.rel_l2(dpos.cpu(), g3[:, extra:].sum(0)) < 1e-6
+    assert O.rel_l2(dextra.cpu(), g3[:, :extra].sum(0)) < 1e-6
+    assert torch.equal(dyp.float().cpu(), r16(g3[:, extra:]).reshape(-1, D))
+    assert O.rel_l2(dbias.cpu(), r16(g3[:, extra:]).sum((0, 1))) < 1e-5

@@ -1,0 +1,100 @@
+"""CPU-side checks (no GPU): module surface / checkpoint-key contract, config derivations, the LR
+schedule against the reference's trace, the C-ABI library's exported symbols, and that the
+product path refuses to run without a device instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from vitamd import lib
+    header = open(os.path.join(ROOT, "include", "vitamd.h")).read()
+    declared = set(re.findall(r"\bint\s+(vitamd_\w+)\s*\(", header))
+    assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
+    if not os.path.exists(lib.LIB_PATH):
+        lib.build()
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(dll, name), name
+    assert lib.load().vitamd_abi_version() == lib.ABI_VERSION
+
+
+def test_state_dict_contract_matches_reference_keys_and_shapes():
+    import train_vit as TV
+    for fixture, size, preset, classes in (("vit_s32.pt", 32, "S", 10), ("vit_b224.pt", 224, "B", 1000)):
+        g = load_golden(fixture)
+        m = TV.ViTClassifier(TV.ViTConfig(size, 3, 16, preset, 1, 0.0), num_classes=classes)
+        sd = m.state_dict()
+        assert sorted(sd.keys()) == g["state_keys"]
+        assert {k: list(v.shape) for k, v in sd.items()} == g["state_shapes"]
+        assert sum(p.numel() for p in m.parameters()) == g["n_params"]
+
+
+def test_transformer_surface():
+    import transformer as T
+    cfg = T.transformer_configs["B"](block_size=197, dropout=0.0)
+    assert (cfg.n_layers, cfg.n_heads, cfg.n_embd, cfg.head_dim, cfg.causal) == (12, 12, 768, 64, False)
+    assert (T.S(block_size=1).n_embd, T.L(block_size=1).n_layers) == (512, 24)
+    c = T.TransformerConfig(n_layers=1, n_heads=2, n_embd=128, block_size=9, causal=True)
+    m = T.Transformer(c)
+    assert m.n_embd == 128 and m.layers[0].multi_attn.n_heads == 2 and m.layers[0].causal   # config fields copied onto modules
+    keys = set(m.state_dict().keys())
+    assert keys == {"layers.0.multi_attn.qkv.weight", "layers.0.multi_attn.qkv.bias", "layers.0.multi_attn.mask",
+                    "layers.0.mlp.0.weight", "layers.0.mlp.0.bias", "layers.0.mlp.2.weight", "layers.0.mlp.2.bias"}
+    mask = m.state_dict()["layers.0.multi_attn.mask"]
+    assert mask.shape == (9, 9) and mask[0, 1] == float("-inf") and mask[1, 0] == 0 and mask[3, 3] == 0
+    old = T.TransformerConfig(n_layers=1, n_heads=2, n_embd=128, block_size=9)
+    del old.__dict__["causal"]          # configs saved before `causal` existed (reference transformer.py:19)
+    assert T.Attention(old).causal is False
+
+
+def test_vit_config_derivations_and_mutation():
+    import train_vit as TV
+    c = TV.ViTConfig(224, 3, 16, "B", 1, 0.0)
+    assert (c.n_patches, c.patch_dim, c.trans_config.block_size) == (196, 768, 197)
+    # the TiTok decoder pattern (reference train_titok.py:31-32): 1x1 "patches" over latents, n_patches overridden
+    d = TV.ViTConfig(32, 512, 1, "S", 256, 0.0)
+    d.n_patches = 32
+    v = TV.ViT(d)
+    assert v.pos_emb.weight.shape == (32, 512) and v.extra_emb.weight.shape == (256, 512)
+    assert v.patch_proj.weight.shape == (512, 512, 1, 1)
+    e = TV.ViT(TV.ViTConfig(256, 3, 16, "B", 0, 0.0))   # ViT-VQGAN: zero extra tokens (reference train_vit_vqgan.py:29)
+    assert e.extra_emb.weight.shape == (0, 768)
+
+
+def test_no_cpu_fallback():
+    import train_vit as TV
+    from vitamd import lib
+    m = TV.ViTClassifier(TV.ViTConfig(32, 3, 16, "S", 1, 0.0), num_classes=10)
+    with pytest.raises(lib.VitamdError):
+        m(torch.randn(2, 3, 32, 32))
+    import transformer as T
+    with pytest.raises(NotImplementedError):
+        T.Transformer(T.S(block_size=5, dropout=0.1))(torch.randn(1, 5, 512))
+
+
+def test_lr_scheduler_reproduces_reference_trace():
+    import utils as U
+    g = load_golden("lr_schedule.pt")
+    p = torch.nn.Parameter(torch.zeros(1))
+    optim = torch.optim.AdamW([p], lr=g["base_lr"])
+    sched = U.get_lr_scheduler(optim, g["warmup_steps"], g["train_steps"], g["min_lr"])
+    for s, lr in enumerate(g["lrs"].tolist()):
+        assert abs(optim.param_groups[0]["lr"] - lr) < 1e-12, (s, optim.param_groups[0]["lr"], lr)
+        optim.step()
+        sched.step()
+    assert U.get_params_str(torch.nn.Linear(1000, 1000)) == "1.0M"
+
+
+def test_shard_batch():
+    from vitamd.ddp import shard_batch
+    for n, w in ((2048, 8), (10, 4), (7, 8)):
+        spans = [shard_batch(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

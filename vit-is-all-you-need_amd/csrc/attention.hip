@@ -1,0 +1,365 @@
+// Scaled-dot-product attention forward / backward for the packed fused-QKV layout of the
+// reference (transformer.py:26-29): qkv [B, N, 3, H, 64] bf16 straight out of the QKV GEMM,
+// output o [B, N, H*64] bf16 — the einops split/merge copies of transformer.py:27,29 never exist.
+// softmax(q k^T / sqrt(dh) [+ causal -inf mask, transformer.py:22-25]) v ; dh = 64 ; N <= 512.
+//
+// gfx950 design.  One workgroup (4 waves) per (batch, head); the whole K/V (or Q/dO) of the head
+// sits in LDS as [N][64] bf16 tiles (128-B rows, LDS-DMA staged, chunk index XOR-swizzled so BOTH
+// the row reads (ds_read_b128) and the transposed reads (ds_read_b64_tr_b16) are conflict-free:
+// tools/lds_banks.py).  Each wave owns 32-row blocks of the "lane side" matrix and keeps its
+// fragments in registers.  mfma_f32_32x32x16_bf16 with the reduction-side index on the accumulator
+// ROWS, so an accumulator tile converts in place into the B operand of the next MFMA
+// (cdna guide section 3, "accumulator tile as the next MFMA's operand") — softmax never leaves registers.
+//
+//   forward : lane = query.  S^T = K.Q^T ; online softmax ; O^T += V^T.P^T
+//   bwd dQ  : lane = query.  S^T = K.Q^T ; dP^T = V.dO^T ; dS^T = P^T o (dP^T - delta) ; dQ^T += K^T.dS^T
+//   bwd dKV : lane = key.    S = Q.K^T ; dP = dO.V^T ; dV^T += dO^T.P ; dK^T += Q^T.dS
+// Scores are recomputed from Q, K and the forward's log-sum-exp (flash-attention backward).
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int MAX_N = 512;
+constexpr float NEG_BIG = -1.0e30f;
+
+typedef LDS_AS bf16x4* lds_bf16x4_ptr;
+
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 3) & 3); }
+
+// Stage rows [0, npad) of a [N][64]-per-head matrix (row stride ld elements) into an LDS tile.
+// Rows >= N re-read row N-1 (finite data; masked by the callers).
+__device__ __forceinline__ void stage_tile(const __bf16* __restrict__ g, int ld, int N, int npad, char* lds, int wave, int lane) {
+  const int pieces = npad / 8;
+  for (int pc = wave; pc < pieces; pc += 4) {
+    const int row = pc * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ swz(row);
+    const int grow = min(row, N - 1);
+    glds16(g + (size_t)grow * ld + logical * 8, lds + pc * 1024);
+  }
+}
+
+// A-operand fragment by ROW read: element j = Y[32T + (lane&31)][16kk + 8(lane>>5) + j]
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int T, int kk, int lane) {
+  const int rr = lane & 31;
+  const int chunk = (2 * kk + (lane >> 5)) ^ swz(rr);
+  return *(const bf16x8*)(tile + T * 4096 + rr * 128 + (chunk << 4));
+}
+
+// A-operand fragment by TRANSPOSED read, in the k order of an accumulator-derived B operand:
+// element j = Y[32T + 16s + 8(j>>2) + 4(lane>>5) + (j&3)][32dt + (lane&31)]
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int T, int s, int dt, int lane) {
+  const int h = lane >> 5, colhalf = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int chunk = 4 * dt + 2 * colhalf + (pp >> 1);
+  bf16x4 part[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rloc = 16 * s + 8 * u + 4 * h + qq;  // row inside the 32-row tile
+    const int f = (((qq >> 1) & 1) << 2) | (2 * s + u);
+    part[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + T * 4096 + rloc * 128 + ((chunk ^ f) << 4) + (pp & 1) * 8));
+  }
+  return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// registers 8s..8s+7 of a 32x32 accumulator -> bf16 B-operand fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& x, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (__bf16)x[8 * s + j];
+  return f;
+}
+
+// lane-side fragments of a 32-row block: element j = X[r0 + (lane&31)][16kk + 8(lane>>5) + j]
+__device__ __forceinline__ void load_lane_frags(const __bf16* __restrict__ g, int ld, int N, int r0, int lane, bf16x8 (&f)[4]) {
+  const int row = min(r0 + (lane & 31), N - 1);
+  const __bf16* p = g + (size_t)row * ld + 8 * (lane >> 5);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) f[kk] = *(const bf16x8*)(p + 16 * kk);
+}
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// store a transposed 64x32 accumulator pair  acc[dt][reg] = X^T[d][row]  as X[row][d] bf16, scaled
+__device__ __forceinline__ void store_rows_T(__bf16* __restrict__ g, int ld, int N, int r0, int lane, const f32x16 (&acc)[2], float scale) {
+  const int row = r0 + (lane & 31);
+  if (row >= N) return;
+  __bf16* p = g + (size_t)row * ld + 4 * (lane >> 5);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      u32x2 o = {pack_bf16x2(acc[dt][4 * u] * scale, acc[dt][4 * u + 1] * scale),
+                 pack_bf16x2(acc[dt][4 * u + 2] * scale, acc[dt][4 * u + 3] * scale)};
+      *(u32x2*)(p + 32 * dt + 8 * u) = o;
+    }
+}
+
+struct AttnArgs {
+  const __bf16* qkv;   // [B, N, 3, H, 64]
+  __bf16* o;           // fwd out / bwd in  [B, N, H*64]
+  float* lse2;         // [B, H, N] log2-domain log-sum-exp of the scaled scores
+  const __bf16* d_o;   // bwd: [B, N, H*64]
+  __bf16* dqkv;        // bwd: [B, N, 3, H, 64]
+  float* delta;        // bwd: [B, H, N] rowsum(dO o O)
+  int B, N, H;
+  int causal;
+  float scale_log2e;   // (1/sqrt(dh)) * log2(e)
+  float scale;         // 1/sqrt(dh)
+};
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  const int nt = (N + 31) / 32, npad = nt * 32;
+  char* ktile = smem;
+  char* vtile = smem + npad * 128;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  stage_tile(qbase + D, D3, N, npad, ktile, wave, lane);
+  stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float c = a.scale_log2e;
+  for (int qb = wave; qb < nt; qb += 4) {
+    const int q0 = qb * 32;
+    const int qrow = q0 + (lane & 31);
+    bf16x8 qf[4];
+    load_lane_frags(qbase, D3, N, q0, lane, qf);
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m = NEG_BIG, l = 0.f;
+    const int t_end = a.causal ? min(nt, qb + 1) : nt;  // key tiles above the diagonal contribute nothing
+    for (int T = 0; T < t_end; ++T) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s, 0, 0, 0);
+      float tmax = NEG_BIG;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * T + acc_row(r, lane);
+        const bool ok = key < N && (!a.causal || key <= qrow);
+        s[r] = ok ? s[r] * c : NEG_BIG;
+        tmax = fmaxf(tmax, s[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(m, tmax);
+      const float alpha = exp2f(m - mnew);
+      m = mnew;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = exp2f(s[r] - mnew);
+        psum += s[r];
+      }
+      l = l * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 pf = acc_to_frag(s, sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vtile, T, sidx, dt, lane), pf, oacc[dt], 0, 0, 0);
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    store_rows_T(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv);
+    if (lane < 32 && qrow < N) a.lse2[((size_t)b * a.H + hh) * N + qrow] = m + log2f(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward, dQ
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  const int nt = (N + 31) / 32, npad = nt * 32;
+  char* ktile = smem;
+  char* vtile = smem + npad * 128;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  stage_tile(qbase + D, D3, N, npad, ktile, wave, lane);
+  stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float c = a.scale_log2e;
+  const __bf16* obase = a.o + (size_t)b * N * D + hh * DH;
+  const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  for (int qb = wave; qb < nt; qb += 4) {
+    const int q0 = qb * 32;
+    const int qrow = q0 + (lane & 31);
+    bf16x8 qf[4], dof[4], of[4];
+    load_lane_frags(qbase, D3, N, q0, lane, qf);
+    load_lane_frags(dobase, D, N, q0, lane, dof);
+    load_lane_frags(obase, D, N, q0, lane, of);
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[kk][j] * (float)of[kk][j];
+    delta += __shfl_xor(delta, 32, 64);
+    const size_t stat = ((size_t)b * a.H + hh) * N + min(qrow, N - 1);
+    const float lse2 = a.lse2[stat];
+    if (lane < 32 && qrow < N) a.delta[stat] = delta;
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    const int t_end = a.causal ? min(nt, qb + 1) : nt;
+    for (int T = 0; T < t_end; ++T) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vtile, T, kk, lane), dof[kk], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * T + acc_row(r, lane);
+        const bool ok = key < N && (!a.causal || key <= qrow);
+        const float p = ok ? exp2f(s[r] * c - lse2) : 0.f;
+        s[r] = p * (dp[r] - delta);  // dS^T (the 1/sqrt(dh) factor is applied once at the end)
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 dsf = acc_to_frag(s, sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ktile, T, sidx, dt, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    store_rows_T(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward, dK and dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  const int nt = (N + 31) / 32, npad = nt * 32;
+  char* qtile = smem;
+  char* dotile = smem + npad * 128;
+  float* lse_s = (float*)(smem + 2 * npad * 128);
+  float* delta_s = lse_s + npad;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  stage_tile(qbase, D3, N, npad, qtile, wave, lane);
+  stage_tile(dobase, D, N, npad, dotile, wave, lane);
+  for (int i = threadIdx.x; i < npad; i += 256) {
+    const size_t stat = ((size_t)b * a.H + hh) * N + min(i, N - 1);
+    lse_s[i] = a.lse2[stat];
+    delta_s[i] = a.delta[stat];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float c = a.scale_log2e;
+  for (int kb = wave; kb < nt; kb += 4) {
+    const int k0 = kb * 32;
+    const int krow = k0 + (lane & 31);
+    bf16x8 kf[4], vf[4];
+    load_lane_frags(qbase + D, D3, N, k0, lane, kf);
+    load_lane_frags(qbase + 2 * D, D3, N, k0, lane, vf);
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const int t_beg = a.causal ? kb : 0;  // queries before the key block never attend to it
+    for (int T = t_beg; T < nt; ++T) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, T, kk, lane), kf[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, T, kk, lane), vf[kk], dp, 0, 0, 0);
+      }
+      f32x16 pmat;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qr = 32 * T + 8 * u + 4 * (lane >> 5);
+        const f32x4 lse4 = *(const f32x4*)(lse_s + qr);
+        const f32x4 del4 = *(const f32x4*)(delta_s + qr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * u + i, query = qr + i;
+          const bool ok = query < N && krow < N && (!a.causal || krow <= query);
+          const float p = ok ? exp2f(s[r] * c - lse4[i]) : 0.f;
+          pmat[r] = p;
+          s[r] = p * (dp[r] - del4[i]);
+        }
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 pf = acc_to_frag(pmat, sidx);
+        const bf16x8 dsf = acc_to_frag(s, sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dotile, T, sidx, dt, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, T, sidx, dt, lane), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    __bf16* dbase = a.dqkv + (size_t)b * N * D3 + hh * DH;
+    store_rows_T(dbase + D, D3, N, k0, lane, dk, a.scale);
+    store_rows_T(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f);
+  }
+}
+
+int check(const AttnArgs& a) {
+  if (a.B <= 0 || a.N <= 0 || a.H <= 0 || a.N > MAX_N) return VITAMD_ERR_SHAPE;
+  return VITAMD_OK;
+}
+
+template <typename K>
+int set_lds(K kern, int bytes) {
+  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal, void* stream) {
+  if (head_dim != DH) return VITAMD_ERR_SHAPE;
+  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f};
+  if (int e = check(a)) return e;
+  if (!qkv || !o || !lse2) return VITAMD_ERR_ARG;
+  const int npad = (N + 31) / 32 * 32, lds = 2 * npad * 128;
+  if (int e = set_lds(attn_fwd_kernel, lds)) return e;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, const void* d_o, void* dqkv, float* delta,
+                                    int B, int N, int H, int head_dim, int causal, void* stream) {
+  if (head_dim != DH) return VITAMD_ERR_SHAPE;
+  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, (float*)lse2, (const __bf16*)d_o, (__bf16*)dqkv, delta, B, N, H, causal,
+             0.125f * 1.4426950408889634f, 0.125f};
+  if (int e = check(a)) return e;
+  if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta) return VITAMD_ERR_ARG;
+  const int npad = (N + 31) / 32 * 32;
+  const int lds1 = 2 * npad * 128, lds2 = 2 * npad * 128 + 2 * npad * 4;
+  if (int e = set_lds(attn_bwd_dq_kernel, lds1)) return e;
+  if (int e = set_lds(attn_bwd_dkv_kernel, lds2)) return e;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(256), lds1, (hipStream_t)stream, a);   // also writes delta
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(256), lds2, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}

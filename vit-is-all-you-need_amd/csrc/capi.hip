@@ -1,0 +1,20 @@
+// extern "C" entry points of libvitamd.so that wrap C++ argument blocks (see include/vitamd.h).
+#include "common.h"
+#include "vitamd_internal.h"
+#include "../../include/vitamd.h"
+
+extern "C" int vitamd_abi_version(void) { return 1; }
+
+extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
+                                   float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
+                                   int tile, void* stream) {
+  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile};
+  if (tile != 0 && tile != 128 && tile != 256) return VITAMD_ERR_ARG;
+  return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
+}
+
+extern "C" int vitamd_gemm_tn_bf16(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
+                                   int splits, void* stream) {
+  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits};
+  return vitamd_gemm_tn_impl(a, (hipStream_t)stream);
+}

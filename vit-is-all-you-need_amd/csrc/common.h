@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;      // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;    // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+#define VITAMD_OK 0
+#define VITAMD_ERR_SHAPE 1
+#define VITAMD_ERR_ARG 2
+#define VITAMD_ERR_LAUNCH 3
+
+// fp32 -> bf16 round-to-nearest-even (plain cast: hipcc emits v_cvt_pk_bf16_f32, NaN-safe)
+__device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }
+__device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
+__device__ __forceinline__ float round_bf16(float x) { return (float)(__bf16)x; }
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ float bf16lo(unsigned int u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16hi(unsigned int u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gptr, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+// erf with |abs err| < 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp, one v_rcp, 5 fma.
+// Outputs are rounded to bf16 (2^-9 relative) so this is exact for our purposes.
+__device__ __forceinline__ float fast_erf(float x) {
+  float ax = __builtin_fabsf(x);
+  float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  float e = __expf(-ax * ax);
+  float r = 1.0f - p * e;
+  return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fwd(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+  float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// bijective XCD-aware remap of a linear workgroup id: consecutive remapped ids share an XCD
+// (blocks b and b+8 share an XCD under round-robin dispatch).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}

@@ -1,0 +1,174 @@
+// Small HBM-bound helpers around the GEMMs: dtype casts, weight transpose, patch gather (im2col),
+// column sums (bias gradients) and the patch-embed backward reduction.
+#include "common.h"
+
+namespace {
+
+// fp32 -> bf16, 8 elements per lane per iteration (32-B loads, 16-B stores)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n8, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const f32x4 a = *(const f32x4*)(in + i * 8), b = *(const f32x4*)(in + i * 8 + 4);
+    u32x4 o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    *(u32x4*)(out + i * 8) = o;
+  }
+  if (blockIdx.x == 0) for (size_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) out[i] = f2bf(in[i]);
+}
+
+// W fp32 [N,K] -> Wb bf16 [N,K] (optional) and WbT bf16 [K,N] (optional); 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, __bf16* __restrict__ wb,
+                                                             __bf16* __restrict__ wbt, int N, int K) {
+  __shared__ float tile[64][65];
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int n = n0 + r, k = k0 + tx;
+    float v = 0.f;
+    if (n < N && k < K) {
+      v = w[(size_t)n * K + k];
+      if (wb) wb[(size_t)n * K + k] = f2bf(v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (wbt) {
+    for (int r = ty; r < 64; r += 4) {
+      const int k = k0 + r, n = n0 + tx;
+      if (k < K && n < N) wbt[(size_t)k * N + n] = f2bf(tile[tx][r]);
+    }
+  }
+}
+
+// images fp32 [B,C,H,W] -> patches bf16 [B*gh*gw, C*p*p], patch vector order (c,kh,kw)
+// (the contraction order of Conv2d(kernel=stride=p), reference train_vit.py:34,39).  One thread per
+// 4 consecutive kw: 16-B fp32 loads along an image row, 8-B bf16 stores along the patch vector.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, __bf16* __restrict__ out,
+                                                     int B, int C, int H, int W, int p) {
+  const int gh = H / p, gw = W / p, pd = C * p * p, p4 = p / 4;
+  const size_t total = (size_t)B * gh * gw * (pd / 4);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    // decompose so consecutive threads walk an image row: (b, c, y = ph*p+kh, pw, kw4)
+    size_t t = i;
+    const int kw4 = t % p4; t /= p4;
+    const int pw = t % gw; t /= gw;
+    const int kh = t % p; t /= p;
+    const int ph = t % gh; t /= gh;
+    const int c = t % C; const int b = t / C;
+    const f32x4 v = *(const f32x4*)(img + (((size_t)b * C + c) * H + ph * p + kh) * W + pw * p + kw4 * 4);
+    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2*)(out + ((size_t)(b * gh + ph) * gw + pw) * pd + (c * p + kh) * p + kw4 * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void im2col_generic_kernel(const float* __restrict__ img, __bf16* __restrict__ out,
+                                                             int B, int C, int H, int W, int p) {
+  const int gh = H / p, gw = W / p, pd = C * p * p;
+  const size_t total = (size_t)B * gh * gw * pd;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    size_t t = i;
+    const int kw = t % p; t /= p;
+    const int kh = t % p; t /= p;
+    const int c = t % C; t /= C;
+    const int pw = t % gw; t /= gw;
+    const int ph = t % gh; const int b = t / gh;
+    out[i] = f2bf(img[(((size_t)b * C + c) * H + ph * p + kh) * W + pw * p + kw]);
+  }
+}
+
+// colsum[n] += sum_m X[m,n]  (X bf16 [M, ld]); each block owns a row slab, one shaped atomic per column
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ x, float* __restrict__ out, int M, int N, int ld, int rows_per_block) {
+  const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
+  const int n = (blockIdx.x * 256 + threadIdx.x) * 2;  // two columns per thread (4-B loads)
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int m = m_lo; m < m_hi; ++m) {
+    const unsigned int v = *(const unsigned int*)(x + (size_t)m * ld + n);
+    s0 += bf16lo(v); s1 += bf16hi(v);
+  }
+  atomicAdd(out + n, s0);
+  if (n + 1 < N) atomicAdd(out + n + 1, s1);
+}
+
+// Patch-embed backward reduction over the batch (reference train_vit.py:41-44 backward):
+//   g fp32 [B, seq, D] (gradient at the transformer input)
+//   dpos[p]   = sum_b g[b, extra+p]      dextra[e] = sum_b g[b, e]
+//   dyp bf16 [B*np, D] = bf16(g[b, extra+p])  (compact rows for the conv weight-gradient GEMM)
+//   dbias[n] += sum_{b,p} bf16(g[b, extra+p, n])
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, float* __restrict__ dpos,
+                                                        float* __restrict__ dextra, __bf16* __restrict__ dyp,
+                                                        float* __restrict__ dbias, int B, int seq, int extra, int D) {
+  const int t = blockIdx.x;  // token position
+  const int np = seq - extra;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float v = g[((size_t)b * seq + t) * D + c];
+      s += v;
+      if (t >= extra) {
+        const __bf16 vb = f2bf(v);
+        dyp[((size_t)b * np + (t - extra)) * D + c] = vb;
+        sb += bf2f(vb);
+      }
+    }
+    if (t < extra) dextra[(size_t)t * D + c] = s;
+    else {
+      dpos[(size_t)(t - extra) * D + c] = s;
+      atomicAdd(dbias + c, sb);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vitamd_cast_f32_bf16(const float* in, void* out_bf16, long n, void* stream) {
+  if (n <= 0) return n == 0 ? VITAMD_OK : VITAMD_ERR_SHAPE;
+  if (!in || !out_bf16) return VITAMD_ERR_ARG;
+  const size_t n8 = (size_t)n / 8;
+  int grid = (int)((n8 + 255) / 256); grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (__bf16*)out_bf16, n8, (size_t)n);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+extern "C" int vitamd_cast_transpose_weight(const float* w, void* wb, void* wbt, int N, int K, void* stream) {
+  if (N <= 0 || K <= 0) return VITAMD_ERR_SHAPE;
+  if (!w || (!wb && !wbt)) return VITAMD_ERR_ARG;
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wb, (__bf16*)wbt, N, K);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+extern "C" int vitamd_im2col_bf16(const float* img, void* out_bf16, int B, int C, int H, int W, int p, void* stream) {
+  if (B <= 0 || C <= 0 || p <= 0 || H < p || W < p) return VITAMD_ERR_SHAPE;
+  if (!img || !out_bf16) return VITAMD_ERR_ARG;
+  const int gh = H / p, gw = W / p;
+  if (p % 4 == 0 && W % 4 == 0) {
+    const size_t total = (size_t)B * gh * gw * (C * p * p / 4);
+    int grid = (int)((total + 255) / 256); grid = grid > 8192 ? 8192 : grid;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (__bf16*)out_bf16, B, C, H, W, p);
+  } else {
+    const size_t total = (size_t)B * gh * gw * C * p * p;
+    int grid = (int)((total + 255) / 256); grid = grid > 8192 ? 8192 : grid;
+    hipLaunchKernelGGL(im2col_generic_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (__bf16*)out_bf16, B, C, H, W, p);
+  }
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+extern "C" int vitamd_colsum_bf16(const void* x_bf16, float* out, int M, int N, int ld, void* stream) {
+  if (M <= 0 || N <= 0 || ld < N || (ld & 1)) return VITAMD_ERR_SHAPE;
+  if (!x_bf16 || !out) return VITAMD_ERR_ARG;
+  const int gx = (N + 511) / 512;
+  int gy = 1024 / gx; if (gy < 1) gy = 1;
+  int rpb = (M + gy - 1) / gy; if (rpb < 16) rpb = 16;
+  gy = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_bf16, out, M, N, ld, rpb);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+extern "C" int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16, float* dbias, int B, int seq,
+                                int extra, int D, void* stream) {
+  if (B <= 0 || seq <= 0 || extra < 0 || extra > seq || D <= 0) return VITAMD_ERR_SHAPE;
+  if (!g || (seq > extra && (!dpos || !dyp_bf16 || !dbias)) || (extra > 0 && !dextra)) return VITAMD_ERR_ARG;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(seq), dim3(256), 0, (hipStream_t)stream, g, dpos, dextra, (__bf16*)dyp_bf16, dbias, B, seq, extra, D);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}

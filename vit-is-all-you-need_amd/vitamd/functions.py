@@ -1,0 +1,278 @@
+"""autograd.Function glue: each Function strings libvitamd kernels together for one reference
+module's forward and hand-written backward.  dtype flow = the reference's autocast flow with bf16
+as the low-precision type: fp32 residual stream and LayerNorm, bf16 GEMM /
+attention / GELU operands and outputs, fp32 accumulation, fp32 parameter gradients.
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class WeightCache:
+    """bf16 (and transposed bf16) copies of fp32 parameters, refreshed when the parameter's
+    version counter changes (i.e. after every optimiser step) — autocast's per-step weight cast,
+    reference train_vit.py:100.  Entries are tied to the parameter OBJECT (weak reference), never
+    to its address: a freed parameter's storage may be handed to a different one."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, w: torch.Tensor, want_t: bool):
+        key = id(w)
+        ent = self._c.get(key)
+        ver = w._version
+        if ent is not None and ent[0]() is w and ent[1] == ver and ent[2] == w.data_ptr() and (ent[4] is not None or not want_t):
+            return ent[3], ent[4]
+        w2 = w.detach()
+        if w2.dim() != 2:
+            w2 = w2.reshape(w2.shape[0], -1)
+        wb, wbt = ops.cast_weight(w2.contiguous(), True, want_t)
+        if len(self._c) > 4096:
+            self._c = {k: v for k, v in self._c.items() if v[0]() is not None}
+        self._c[key] = (weakref.ref(w), ver, w.data_ptr(), wb, wbt)
+        return wb, wbt
+
+    def clear(self):
+        self._c.clear()
+
+
+WEIGHTS = WeightCache()
+
+
+def _f32c(t):
+    return t.detach().to(F32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# one pre-LN transformer layer (reference transformer.py:42-45)
+# ------------------------------------------------------------------------------------------------
+def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad):
+    """x0 fp32 [M,D] -> x2 fp32 [M,D] and the tensors backward needs."""
+    wqkv_b, _ = WEIGHTS.get(wqkv, need_grad)
+    w1_b, _ = WEIGHTS.get(w1, need_grad)
+    w2_b, _ = WEIGHTS.get(w2, need_grad)
+    _, a, mean1, rstd1 = ops.layernorm_fwd(x0)                                   # LN1            transformer.py:43
+    qkv = ops.gemm_nt(a, wqkv_b, ops.EPI_BIAS_BF16, bias=bqkv)                   # fused QKV      transformer.py:27
+    o, lse = ops.attention_fwd(qkv, B, N, H, causal)                             # SDPA           transformer.py:28-29
+    x1, bln, mean2, rstd2 = ops.layernorm_fwd(x0, addend=o)                      # residual + LN2 transformer.py:43-44
+    pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU, bias=b1)                       # fc1 + GELU     transformer.py:37-38
+    x2 = ops.gemm_nt(h, w2_b, ops.EPI_RESID_F32, bias=b2, aux=x1)                # fc2 + residual transformer.py:39,44
+    saved = (x0, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, bln, pre, h) if need_grad else None
+    return x2, saved
+
+
+def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, dy2=None, db2=None, emit_bf16=False, emit_colsum=None):
+    """g2 fp32 [M,D] = dL/dx2.  Returns g0 and the six parameter gradients (fp32).
+    dy2/db2: bf16(g2) and its column sums if a previous kernel already produced them.
+    emit_bf16/emit_colsum: also return bf16(g0) (+ accumulate its column sums) for the layer below."""
+    x0, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, bln, pre, h = saved
+    dev = g2.device
+    D = x0.shape[1]
+    _, wqkv_t = WEIGHTS.get(wqkv, True)
+    _, w1_t = WEIGHTS.get(w1, True)
+    _, w2_t = WEIGHTS.get(w2, True)
+    if dy2 is None:
+        dy2 = ops.cast_bf16(g2)
+        db2 = ops.colsum(dy2)
+    # ---- MLP
+    dW2 = torch.zeros((D, 4 * D), dtype=F32, device=dev)
+    ops.gemm_tn(dy2, h, dW2)
+    db1 = torch.zeros((4 * D,), dtype=F32, device=dev)
+    dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)            # dgrad fc2 . gelu'
+    dW1 = torch.zeros((4 * D, D), dtype=F32, device=dev)
+    ops.gemm_tn(dpre, bln, dW1)
+    dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
+    g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True)
+    # ---- attention
+    dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal)
+    dbqkv = ops.colsum(dqkv)
+    dWqkv = torch.zeros((3 * D, D), dtype=F32, device=dev)
+    ops.gemm_tn(dqkv, a, dWqkv)
+    da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
+    g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum)
+    return g0, g0b, (dWqkv, dbqkv, dW1, db1, dW2, db2)
+
+
+class TransformerLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, w1, b1, w2, b2, n_heads, causal):
+        B, N, D = x.shape
+        need_grad = any(ctx.needs_input_grad)
+        x2, saved = layer_forward(_f32c(x).view(B * N, D), wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads,
+                                  causal, need_grad)
+        if need_grad:
+            ctx.save_for_backward(*saved)
+            ctx.weights = (wqkv, w1, w2)
+        ctx.meta = (B, N, D, n_heads, causal, x.dtype)
+        return x2.view(B, N, D).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D, H, causal, xdtype = ctx.meta
+        wqkv, w1, w2 = ctx.weights
+        g0, _, (dWqkv, dbqkv, dW1, db1, dW2, db2) = layer_backward(_f32c(g).view(B * N, D), ctx.saved_tensors, wqkv, w1, w2,
+                                                                   B, N, H, causal)
+        return g0.view(B, N, D).to(xdtype), dWqkv, dbqkv, dW1, db1, dW2, db2, None, None
+
+
+class TransformerStackFn(torch.autograd.Function):
+    """All layers of reference transformer.Transformer (transformer.py:52-54) in one autograd node:
+    the backward of layer i+1's first LayerNorm hands bf16(g) and its column sums straight to layer
+    i's fc2 weight/bias gradient, so no separate cast / column-sum passes exist between layers."""
+
+    @staticmethod
+    def forward(ctx, x, n_heads, causal, *params):
+        B, N, D = x.shape
+        L = len(params) // 6
+        need_grad = any(ctx.needs_input_grad)
+        cur = _f32c(x).view(B * N, D)
+        saved_all = []
+        for i in range(L):
+            wqkv, bqkv, w1, b1, w2, b2 = params[6 * i: 6 * i + 6]
+            cur, saved = layer_forward(cur, wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads, causal, need_grad)
+            if need_grad:
+                saved_all.extend(saved)
+        if need_grad:
+            ctx.save_for_backward(*saved_all)
+            ctx.params = params
+        ctx.meta = (B, N, D, n_heads, causal, L, x.dtype)
+        return cur.view(B, N, D).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D, H, causal, L, xdtype = ctx.meta
+        saved_all = ctx.saved_tensors
+        params = ctx.params
+        n_saved = len(saved_all) // L
+        cur = _f32c(g).view(B * N, D)
+        grads = [None] * (6 * L)
+        dy2, db2 = None, None
+        for i in reversed(range(L)):
+            wqkv, _, w1, _, w2, _ = params[6 * i: 6 * i + 6]
+            nxt_db2 = torch.zeros((D,), dtype=F32, device=cur.device) if i > 0 else None
+            cur, g0b, pg = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal,
+                                          dy2=dy2, db2=db2, emit_bf16=i > 0, emit_colsum=nxt_db2)
+            grads[6 * i: 6 * i + 6] = pg
+            dy2, db2 = g0b, nxt_db2
+        return (cur.view(B, N, D).to(xdtype), None, None, *grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused-QKV attention as a stand-alone module (reference transformer.py:26-29)
+# ------------------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, n_heads, causal):
+        B, N, D = x.shape
+        need_grad = any(ctx.needs_input_grad)
+        wb, _ = WEIGHTS.get(wqkv, need_grad)
+        xb = ops.cast_bf16(_f32c(x).view(B * N, D))
+        qkv = ops.gemm_nt(xb, wb, ops.EPI_BIAS_BF16, bias=_f32c(bqkv))
+        o, lse = ops.attention_fwd(qkv, B, N, n_heads, causal)
+        if need_grad:
+            ctx.save_for_backward(xb, qkv, o, lse)
+            ctx.wqkv = wqkv
+        ctx.meta = (B, N, D, n_heads, causal, x.dtype)
+        return o.view(B, N, D).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D, H, causal, xdtype = ctx.meta
+        xb, qkv, o, lse = ctx.saved_tensors
+        _, wt = WEIGHTS.get(ctx.wqkv, True)
+        d_o = ops.cast_bf16(_f32c(g).view(B * N, D))
+        dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal)
+        dW = torch.zeros((3 * D, D), dtype=F32, device=g.device)
+        ops.gemm_tn(dqkv, xb, dW)
+        db = ops.colsum(dqkv)
+        dx = ops.gemm_nt(dqkv, wt, ops.EPI_BIAS_BF16)
+        return dx.view(B, N, D).to(xdtype), dW, db, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# patch embedding + token assembly (reference train_vit.py:38-44)
+# ------------------------------------------------------------------------------------------------
+class PatchEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, conv_w, conv_b, pos_w, extra_w, patch, n_patches):
+        B = images.shape[0]
+        D = conv_w.shape[0]
+        extra = extra_w.shape[0]
+        seq = n_patches + extra
+        need_grad = any(ctx.needs_input_grad[1:])
+        patches = ops.im2col(_f32c(images), patch)  # [B*np, C*p*p] bf16
+        if patches.shape[0] != B * n_patches:
+            raise ops._lib.VitamdError(f"patch grid gives {patches.shape[0] // B} patches, config says {n_patches}")
+        wb, _ = WEIGHTS.get(conv_w, False)
+        x = torch.empty((B * seq, D), dtype=F32, device=images.device)
+        ops.gemm_nt(patches, wb, ops.EPI_PATCH_F32, bias=_f32c(conv_b), aux=_f32c(pos_w)[:n_patches].contiguous(), out=x,
+                    n_patches=n_patches, seq=seq, extra=extra)
+        x = x.view(B, seq, D)
+        if extra > 0:
+            x[:, :extra] = extra_w.detach().to(F32)  # learned extra tokens are PREPENDED (train_vit.py:43-44)
+        if need_grad:
+            ctx.save_for_backward(patches)
+        ctx.meta = (B, D, extra, seq, n_patches, tuple(conv_w.shape), pos_w.shape[0])
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        B, D, extra, seq, n_patches, wshape, pos_rows = ctx.meta
+        (patches,) = ctx.saved_tensors
+        dpos, dextra, dyp, dbias = ops.embed_bwd(_f32c(g).view(B * seq, D), B, seq, extra, D)
+        dW = torch.zeros((D, patches.shape[1]), dtype=F32, device=g.device)
+        ops.gemm_tn(dyp, patches, dW)
+        if pos_rows != n_patches:
+            full = torch.zeros((pos_rows, D), dtype=F32, device=g.device)
+            full[:n_patches] = dpos
+            dpos = full
+        return None, dW.view(wshape), dbias, dpos, dextra, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# generic Linear on the kernels (classifier head, reference train_vit.py:51,53)
+# ------------------------------------------------------------------------------------------------
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b through the MFMA GEMM; the output dim is zero-padded to a multiple of 64
+    internally so that it can serve as the reduction dim of the input-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        M, K = x.shape
+        Nout = w.shape[0]
+        Np = _pad64(Nout)
+        dev = x.device
+        wp = torch.zeros((Np, K), dtype=F32, device=dev)
+        wp[:Nout] = w.detach()
+        bp = torch.zeros((Np,), dtype=F32, device=dev)
+        if b is not None:
+            bp[:Nout] = b.detach()
+        wb, wbt = ops.cast_weight(wp, True, True)
+        xb = ops.cast_bf16(_f32c(x))
+        y = ops.gemm_nt(xb, wb, ops.EPI_BIAS_BF16, bias=bp)
+        ctx.save_for_backward(xb, wbt)
+        ctx.meta = (M, K, Nout, Np, x.dtype, b is not None)
+        return y[:, :Nout].to(F32)
+
+    @staticmethod
+    def backward(ctx, g):
+        M, K, Nout, Np, xdtype, has_b = ctx.meta
+        xb, wbt = ctx.saved_tensors
+        gp = torch.zeros((M, Np), dtype=F32, device=g.device)
+        gp[:, :Nout] = g
+        gb = ops.cast_bf16(gp)
+        dx = ops.gemm_nt(gb, wbt, ops.EPI_BIAS_BF16)
+        dWp = torch.zeros((Np, K), dtype=F32, device=g.device)
+        ops.gemm_tn(gb, xb, dWp)
+        db = ops.colsum(gb)[:Nout].clone() if has_b else None
+        return dx.to(xdtype), dWp[:Nout].clone(), db

@@ -1,0 +1,76 @@
+"""ctypes binding of libvitamd.so (C ABI declared in include/vitamd.h).
+
+The library is built in-tree by `csrc/Makefile` (see __graft_entry__.build).  There is no
+fallback: if it is missing, `load()` raises — the product path never routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitamd.so")
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+ABI_VERSION = 1
+
+_c = ctypes
+_P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long
+
+# name -> argtypes ; every function returns int (VITAMD_OK == 0)
+SIGNATURES = {
+    "vitamd_abi_version": [],
+    "vitamd_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vitamd_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vitamd_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "vitamd_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vitamd_cast_f32_bf16": [_P, _P, _L, _P],
+    "vitamd_cast_transpose_weight": [_P, _P, _P, _I, _I, _P],
+    "vitamd_im2col_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "vitamd_colsum_bf16": [_P, _P, _I, _I, _I, _P],
+    "vitamd_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+}
+
+ERRORS = {1: "unsupported shape", 2: "bad argument", 3: "HIP launch failure"}
+
+_lib = None
+
+
+class VitamdError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libvitamd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise VitamdError("building libvitamd.so failed")
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once) and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitamdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP kernels are the only implementation of this path; there is no fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    if lib.vitamd_abi_version() != ABI_VERSION:
+        raise VitamdError("libvitamd.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise VitamdError(f"{what}: {ERRORS.get(code, code)}")

@@ -1,0 +1,175 @@
+"""Host wrappers: torch device tensors in, libvitamd.so kernel launches on torch's current HIP stream.
+
+PyTorch is plumbing here (HBM allocation, streams); every computation on the path is a kernel of
+libvitamd.so.  All functions require ROCm device tensors and raise otherwise — no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as _lib
+
+EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32 = range(6)
+LN_EPS = 1e-5
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.VitamdError(f"{name}: expected a ROCm device tensor (the HIP kernels are the only implementation)")
+    if t.dtype != dtype:
+        raise _lib.VitamdError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.VitamdError(f"{name}: must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise _lib.VitamdError(f"{name}: expected {ndim}-d, got {t.dim()}-d")
+    return t
+
+
+# ------------------------------------------------------------------------------------------ GEMMs
+def gemm_nt(a, b, epi, *, bias=None, aux=None, out=None, out2=None, colsum=None, n_patches=0, seq=0, extra=0,
+            out_rows=None, tile=0):
+    """out = epilogue(a[M,K] @ b[N,K]^T).  Returns out (and out2 for EPI_GELU)."""
+    _need(a, BF16, "a", 2); _need(b, BF16, "b", 2)
+    M, K = a.shape
+    N, K2 = b.shape
+    if K != K2:
+        raise _lib.VitamdError(f"gemm_nt: K mismatch {K} vs {K2}")
+    out_dtype = F32 if epi in (EPI_RESID_F32, EPI_PATCH_F32, EPI_F32) else BF16
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
+    _need(out, out_dtype, "out")
+    if epi == EPI_GELU and out2 is None:
+        out2 = torch.empty((M, N), dtype=BF16, device=a.device)
+    if bias is not None:
+        _need(bias, F32, "bias", 1)
+    code = _L().vitamd_gemm_nt_bf16(_p(a), _p(b), _p(out), _p(out2), _p(bias), _p(aux), _p(colsum), M, N, K, N, epi,
+                                    n_patches, seq, extra, tile, _stream())
+    _lib.check(code, f"gemm_nt[M={M},N={N},K={K},epi={epi}]")
+    return (out, out2) if epi == EPI_GELU else out
+
+
+def gemm_tn(l, r, out, splits=0):
+    """out[P,Q] (fp32) += l[R,P]^T @ r[R,Q]."""
+    _need(l, BF16, "l", 2); _need(r, BF16, "r", 2); _need(out, F32, "out", 2)
+    R, P = l.shape
+    R2, Q = r.shape
+    if R != R2 or tuple(out.shape) != (P, Q):
+        raise _lib.VitamdError("gemm_tn: shape mismatch")
+    code = _L().vitamd_gemm_tn_bf16(_p(l), _p(r), _p(out), R, P, Q, P, Q, Q, splits, _stream())
+    _lib.check(code, f"gemm_tn[R={R},P={P},Q={Q}]")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, addend=None):
+    """x fp32 [M,D] (+ addend bf16) -> (x_sum fp32 or x itself, y bf16, mean, rstd)."""
+    _need(x, F32, "x", 2)
+    M, D = x.shape
+    y = torch.empty((M, D), dtype=BF16, device=x.device)
+    mean = torch.empty((M,), dtype=F32, device=x.device)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    x_out = None
+    if addend is not None:
+        _need(addend, BF16, "addend", 2)
+        x_out = torch.empty_like(x)
+    code = _L().vitamd_layernorm_fwd(_p(x), _p(addend), _p(x_out), _p(y), _p(mean), _p(rstd), M, D, LN_EPS, _stream())
+    _lib.check(code, f"layernorm_fwd[M={M},D={D}]")
+    return (x_out if addend is not None else x), y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, g_res=None, want_bf16=False, colsum=None):
+    """g = (g_res or 0) + LN'(dy); returns (g fp32, bf16(g) or None)."""
+    _need(dy, BF16, "dy", 2); _need(x, F32, "x", 2)
+    M, D = x.shape
+    g = torch.empty_like(x)
+    gb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    if g_res is not None:
+        _need(g_res, F32, "g_res", 2)
+    code = _L().vitamd_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(g_res), _p(g), _p(gb), _p(colsum), M, D, _stream())
+    _lib.check(code, f"layernorm_bwd[M={M},D={D}]")
+    return g, gb
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention_fwd(qkv, B, N, H, causal=False):
+    """qkv bf16 [B*N, 3*H*64] (packed (qkv, head, dh)) -> o bf16 [B*N, H*64], lse2 fp32 [B,H,N]."""
+    _need(qkv, BF16, "qkv", 2)
+    D = H * 64
+    if tuple(qkv.shape) != (B * N, 3 * D):
+        raise _lib.VitamdError("attention_fwd: qkv must be [B*N, 3*H*64] (head_dim 64 only)")
+    o = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+    code = _L().vitamd_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, H, 64, int(causal), _stream())
+    _lib.check(code, f"attention_fwd[B={B},N={N},H={H}]")
+    return o, lse
+
+
+def attention_bwd(qkv, o, lse, d_o, B, N, H, causal=False):
+    _need(qkv, BF16, "qkv", 2); _need(o, BF16, "o", 2); _need(d_o, BF16, "d_o", 2); _need(lse, F32, "lse")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    code = _L().vitamd_attention_bwd(_p(qkv), _p(o), _p(lse), _p(d_o), _p(dqkv), _p(delta), B, N, H, 64, int(causal), _stream())
+    _lib.check(code, f"attention_bwd[B={B},N={N},H={H}]")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def cast_bf16(x):
+    _need(x, F32, "x")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.check(_L().vitamd_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "cast_f32_bf16")
+    return out
+
+
+def cast_weight(w, want_plain=True, want_transposed=False):
+    """fp32 [N,K] weight -> (bf16 [N,K] or None, bf16 [K,N] or None)."""
+    _need(w, F32, "w", 2)
+    N, K = w.shape
+    wb = torch.empty((N, K), dtype=BF16, device=w.device) if want_plain else None
+    wbt = torch.empty((K, N), dtype=BF16, device=w.device) if want_transposed else None
+    _lib.check(_L().vitamd_cast_transpose_weight(_p(w), _p(wb), _p(wbt), N, K, _stream()), "cast_transpose_weight")
+    return wb, wbt
+
+
+def im2col(img, p):
+    _need(img, F32, "img", 4)
+    B, C, H, W = img.shape
+    out = torch.empty((B * (H // p) * (W // p), C * p * p), dtype=BF16, device=img.device)
+    _lib.check(_L().vitamd_im2col_bf16(_p(img), _p(out), B, C, H, W, p, _stream()), "im2col")
+    return out
+
+
+def colsum(x, out=None):
+    _need(x, BF16, "x", 2)
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros((N,), dtype=F32, device=x.device)
+    _lib.check(_L().vitamd_colsum_bf16(_p(x), _p(out), M, N, N, _stream()), "colsum")
+    return out
+
+
+def embed_bwd(g, B, seq, extra, D):
+    """g fp32 [B*seq, D] -> dpos [seq-extra, D], dextra [extra, D], dyp bf16 [B*(seq-extra), D], dbias [D]."""
+    _need(g, F32, "g", 2)
+    n_p = seq - extra
+    dev = g.device
+    dpos = torch.empty((n_p, D), dtype=F32, device=dev)
+    dextra = torch.empty((extra, D), dtype=F32, device=dev)
+    dyp = torch.empty((B * n_p, D), dtype=BF16, device=dev)
+    dbias = torch.zeros((D,), dtype=F32, device=dev)
+    _lib.check(_L().vitamd_embed_bwd(_p(g), _p(dpos), _p(dextra) if extra > 0 else None, _p(dyp), _p(dbias), B, seq, extra, D,
+                                     _stream()), "embed_bwd")
+    return dpos, dextra, dyp, dbias
