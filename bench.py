@@ -82,6 +82,7 @@ def cpu_baseline():
     import vit_oracle as O
     import weights as W
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)          # the GPU box grants a 16-core CPU share per GPU; more threads only thrash
     torch.set_num_threads(cores)
     cfg = O.OracleViTConfig.preset(224, 3, 16, "B", 1)
     sd = W.classifier_state(0, 3, 16, cfg.n_patches, 1, cfg.n_layers, cfg.n_embd, 1000)
