@@ -81,7 +81,8 @@ int vitamd_im2col_bf16(const float* img, void* out_bf16, int B, int C, int H, in
 /* out[n] += sum_m X[m,n]  (bias gradients). */
 int vitamd_colsum_bf16(const void* x_bf16, float* out, int M, int N, int ld, void* stream);
 /* Backward of the token assembly train_vit.py:41-44: g fp32 [B,seq,D] -> dpos [seq-extra,D],
- * dextra [extra,D], compact bf16 patch rows dyp [B*(seq-extra),D], dbias[D] += their column sums. */
+ * dextra [extra,D], compact bf16 patch rows dyp [B*(seq-extra),D], dbias[D] = their column sums.
+ * dpos, dextra and dbias are ACCUMULATED into (atomics): zero them for a fresh gradient. */
 int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16, float* dbias, int B, int seq,
                      int extra, int D, void* stream);
 

@@ -33,7 +33,11 @@ def r16(x):
 
 # ------------------------------------------------------------------------------------------ gemm_nt
 @pytest.mark.parametrize("M,N,K,tile", [(256, 256, 64, 256), (512, 768, 768, 256), (320, 1536, 512, 128), (111, 128, 128, 128),
-                                        (1000, 2304, 768, 256), (197 * 4, 768, 3072, 0), (64, 64, 64, 0), (300, 1024, 192, 256)])
+                                        (1000, 2304, 768, 256), (197 * 4, 768, 3072, 0), (64, 64, 64, 0), (300, 1024, 192, 256),
+                                        (256, 128, 32, 1), (512, 768, 768, 1), (1000, 2304, 96, 1), (333, 200, 160, 1),
+                                        (197 * 64, 768, 3072, 0), (197 * 64, 3072, 768, 0), (50432, 2304, 768, 0),
+                                        (256, 256, 32, 4), (512, 768, 768, 4), (1000, 2304, 96, 3), (333, 200, 160, 5), (197 * 64, 768, 3072, 4), (256, 256, 64, 5),
+                                        (256, 256, 64, 2), (512, 768, 768, 2), (1000, 2304, 128, 2), (333, 200, 192, 2), (197 * 64, 768, 3072, 2)])
 def test_gemm_nt_exact_integers(hip, M, N, K, tile):
     from vitamd import ops
     a = ints((M, K), -3, 3, 1)
@@ -44,8 +48,14 @@ def test_gemm_nt_exact_integers(hip, M, N, K, tile):
     assert torch.equal(out.cpu(), ref)
 
 
-def test_gemm_nt_epilogues(hip):
-    from vitamd import ops
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 128, 256])
+def test_gemm_nt_epilogues(hip, tile):
+    import functools
+    from vitamd import ops as _ops
+
+    class ops:  # same API with the tile selector pinned
+        gemm_nt = staticmethod(functools.partial(_ops.gemm_nt, tile=tile))
+        EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32 = range(6)
     M, N, K = 333, 512, 256
     a, b = r16(randn((M, K), 3)), r16(randn((N, K), 4, 0.1))
     bias = randn((N,), 5)

@@ -1,0 +1,22 @@
+"""Timing-only ablations of the 256x256 pipe GEMM: which resource bounds the main loop?"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
+from vitamd import ops
+dev = torch.device("cuda")
+M, D = 256 * 197, 768
+g = torch.Generator(device="cpu").manual_seed(0)
+rb = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev, torch.bfloat16)
+x768, x3072 = rb(M, D), rb(M, 4 * D)
+wqkv, w2 = rb(3 * D, D, scale=0.03), rb(D, 4 * D, scale=0.03)
+def t(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+for name, a, b in (("K=768 N=2304", x768, wqkv), ("K=3072 N=768", x3072, w2)):
+    for tile, what in ((2, "pipe full"), (21, "pipe no MFMA"), (22, "pipe no LDS-DMA"), (3, "deep ring 3"), (4, "deep ring 4"), (5, "deep ring 5"), (256, "old burst kernel")):
+        print(f"{name:14s} {what:18s} {t(lambda: ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, tile=tile)):8.1f} us", flush=True)

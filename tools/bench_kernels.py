@@ -53,13 +53,14 @@ def main():
         print(s, flush=True)
         rows.append(s)
 
-    for tile in (256, 128):
+    wqkv_t = rb(D, 3 * D, scale=0.03)
+    for tile in (2, 256):
         rec(f"gemm_nt qkv  bias   t{tile}", timeit(lambda: ops.gemm_nt(x768, wqkv, ops.EPI_BIAS_BF16, bias=bias3, tile=tile)), 2 * M * D * 3 * D)
         rec(f"gemm_nt fc1  gelu   t{tile}", timeit(lambda: ops.gemm_nt(x768, w1, ops.EPI_GELU, bias=bias4, tile=tile)), 2 * M * D * 4 * D)
         rec(f"gemm_nt fc2  resid  t{tile}", timeit(lambda: ops.gemm_nt(x3072, w2, ops.EPI_RESID_F32, bias=bias1, aux=res, tile=tile)), 2 * M * D * 4 * D)
         rec(f"gemm_nt dfc2 dgelu  t{tile}", timeit(lambda: ops.gemm_nt(x768, w1, ops.EPI_DGELU, aux=x3072, tile=tile)), 2 * M * D * 4 * D)
         rec(f"gemm_nt dfc1 plain  t{tile}", timeit(lambda: ops.gemm_nt(x3072, w2, ops.EPI_BIAS_BF16, tile=tile)), 2 * M * D * 4 * D)
-        rec(f"gemm_nt dqkv plain  t{tile}", timeit(lambda: ops.gemm_nt(x2304, rb(D, 3 * D), ops.EPI_BIAS_BF16, tile=tile)), 2 * M * D * 3 * D)
+        rec(f"gemm_nt dqkv plain  t{tile}", timeit(lambda: ops.gemm_nt(x2304, wqkv_t, ops.EPI_BIAS_BF16, tile=tile)), 2 * M * D * 3 * D)
     dW = torch.zeros(3 * D, D, device=dev)
     rec("gemm_tn wgrad qkv", timeit(lambda: ops.gemm_tn(x2304, x768, dW)), 2 * M * D * 3 * D)
     dW1 = torch.zeros(4 * D, D, device=dev)

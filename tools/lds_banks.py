@@ -71,3 +71,12 @@ if __name__ == "__main__":
         return r * 128 + ((c ^ fa(r)) << 4) + (pp & 1) * 8
     print("ATTN row read b128 :", [b128([arow(l, kk) for l in range(64)]) for kk in range(4)])
     print("ATTN tr read b64   :", [b64([atr(l, s, u, dt) for l in range(64)]) for s in (0, 1) for u in (0, 1) for dt in (0, 1)])
+
+    # GEMM NT, BK=32 tiles: rows of 32 bf16 (64 B = 4 chunks); chunk ^ g[(row>>2)&3], g = [0,2,3,1]
+    G4 = [0, 2, 3, 1]
+
+    def nt32(l, mt):
+        r = mt * 16 + (l & 15)
+        c = l >> 4
+        return r * 64 + ((c ^ G4[(r >> 2) & 3]) << 4)
+    print("NT BK=32 frag read swz / linear  :", b128([nt32(l, 0) for l in range(64)]), b128([(l & 15) * 64 + (l >> 4) * 16 for l in range(64)]))

@@ -36,6 +36,16 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gptr, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
+// same through a buffer descriptor (range-checked: out-of-range lanes write zeros); voff = per-lane
+// byte offset, soff = wave-uniform byte offset.  Kept in a NON-template function on purpose: called
+// from a dependent context hipcc (ROCm 7.2) silently drops the kernel's host stub.
+__device__ __forceinline__ void buf_glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+
 // erf with |abs err| < 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp, one v_rcp, 5 fma.
 // Outputs are rounded to bf16 (2^-9 relative) so this is exact for our purposes.
 __device__ __forceinline__ float fast_erf(float x) {

@@ -15,91 +15,12 @@ namespace {
 
 constexpr int BK = 64;  // bf16 elements per K-tile = 128 B per LDS row
 
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNtArgs p) {
+// Shared epilogue: acc[i][j][r] = C[m][n] with m = m0 + wm*WTM + i*16 + (lane&15),
+// n = n0 + wn*WTN + j*16 + 4*(lane>>4) + r  (A/B swapped MFMA: each lane owns 4 consecutive columns).
+template <int BN, int WM, int WN, int WTM, int WTN, int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn,
+                                              int lane, int tid, char* smem) {
   constexpr int NW = WM * WN;
-  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
-  constexpr int MT = WTM / 16, NT = WTN / 16;   // 16x16 accumulator tiles per wave
-  constexpr int PIECES = (BM + BN) / 8;         // 1-KiB LDS-DMA pieces (8 rows x 128 B) per K-tile
-  constexpr int PPW = PIECES / NW;
-  static_assert(PIECES % NW == 0, "pieces must divide over waves");
-  constexpr int BUF_BYTES = (BM + BN) * 128;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (tile / tiles_n) * BM;
-  const int n0 = (tile % tiles_n) * BN;
-
-  const __bf16* __restrict__ A = (const __bf16*)p.A;
-  const __bf16* __restrict__ B = (const __bf16*)p.B;
-  const int K = p.K;
-
-  // per-lane source pointers of this wave's pieces (row clamped: out-of-range rows re-read the
-  // last valid row; their results are never stored)
-  const __bf16* src[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int piece = wave * PPW + i;
-    const int row = piece * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ (row & 7);
-    if (piece < BM / 8) {
-      const int g = min(m0 + row, p.M - 1);
-      src[i] = A + (size_t)g * K + logical * 8;
-    } else {
-      const int g = min(n0 + row - BM, p.N - 1);
-      src[i] = B + (size_t)g * K + logical * 8;
-    }
-  }
-
-  auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * BUF_BYTES + wave * PPW * 1024;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16(src[i] + kt * BK, base + i * 1024);
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets inside a buffer (ks = 1 flips chunk bit 2 -> byte ^ 64)
-  const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7)) & 7) << 4);
-  const int a_off = wm * WTM * 128 + frag_off;
-  const int b_off = BM * 128 + wn * WTN * 128 + frag_off;
-
-  const int nkt = K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt landed for everyone; everyone finished reading buffer cur^1
-    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-    const char* buf = smem + cur * BUF_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[MT], bfr[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(buf + ((b_off + j * 16 * 128) ^ (ks * 64)));
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(buf + ((a_off + i * 16 * 128) ^ (ks * 64)));
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
-  }
-
-  // ------------------------------------------------------------------ epilogue
   // acc[i][j][r] = C[m][n], m = m0 + wm*WTM + i*16 + (lane&15), n = n0 + wn*WTN + j*16 + 4*(lane>>4) + r
   const int mrow = m0 + wm * WTM + (lane & 15);
   const int ncol = n0 + wn * WTN + 4 * (lane >> 4);
@@ -210,6 +131,423 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNtArgs 
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNtArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+  constexpr int MT = WTM / 16, NT = WTN / 16;   // 16x16 accumulator tiles per wave
+  constexpr int PIECES = (BM + BN) / 8;         // 1-KiB LDS-DMA pieces (8 rows x 128 B) per K-tile
+  constexpr int PPW = PIECES / NW;
+  static_assert(PIECES % NW == 0, "pieces must divide over waves");
+  constexpr int BUF_BYTES = (BM + BN) * 128;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
+
+  const __bf16* __restrict__ A = (const __bf16*)p.A;
+  const __bf16* __restrict__ B = (const __bf16*)p.B;
+  const int K = p.K;
+
+  // per-lane source pointers of this wave's pieces (row clamped: out-of-range rows re-read the
+  // last valid row; their results are never stored)
+  const __bf16* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wave * PPW + i;
+    const int row = piece * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ (row & 7);
+    if (piece < BM / 8) {
+      const int g = min(m0 + row, p.M - 1);
+      src[i] = A + (size_t)g * K + logical * 8;
+    } else {
+      const int g = min(n0 + row - BM, p.N - 1);
+      src[i] = B + (size_t)g * K + logical * 8;
+    }
+  }
+
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * BUF_BYTES + wave * PPW * 1024;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(src[i] + kt * BK, base + i * 1024);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets inside a buffer (ks = 1 flips chunk bit 2 -> byte ^ 64)
+  const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7)) & 7) << 4);
+  const int a_off = wm * WTM * 128 + frag_off;
+  const int b_off = BM * 128 + wn * WTN * 128 + frag_off;
+
+  const int nkt = K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt landed for everyone; everyone finished reading buffer cur^1
+    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const char* buf = smem + cur * BUF_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[MT], bfr[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(buf + ((b_off + j * 16 * 128) ^ (ks * 64)));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(buf + ((a_off + i * 16 * 128) ^ (ks * 64)));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Main kernel: 256x128 output tile, 4 waves (2x2, wave tile 128x64), BK = 32, 3-stage LDS ring
+// (72 KiB) so TWO workgroups share a CU.  Why this shape on gfx950: with one 8-wave / 128-KiB
+// workgroup per CU every workgroup reaches its (HBM-bound) epilogue at the same time and the MFMA
+// pipes idle meanwhile; two independent 4-wave workgroups per CU de-phase naturally — one's
+// epilogue stores / GELU VALU work / barrier and LDS-latency stalls hide under the other's MFMAs
+// (each SIMD hosts one wave of each).  Tiles are streamed by LDS-DMA two K-steps ahead behind a
+// COUNTED s_waitcnt vmcnt (never 0 in the loop) and a raw s_barrier.  LDS rows are 64 B (4 chunks);
+// chunk index XOR g[(row>>2)&3], g = {0,2,3,1}, applied on the source address: conflict-free
+// ds_read_b128 (tools/lds_banks.py).
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_ring_kernel(const GemmNtArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int KS = 32;                         // K-step
+  constexpr int PIECES = (BM + BN) / 16;         // 1-KiB pieces: 16 rows x 64 B
+  constexpr int PPW = PIECES / NW;
+  constexpr int A_ITERS = BM / 16 / NW;          // pieces i < A_ITERS of every wave are A rows
+  static_assert(PIECES % NW == 0 && (BM / 16) % NW == 0, "piece split");
+  constexpr int STAGES = 3;
+  constexpr int STAGE_BYTES = (BM + BN) * 64;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int K = p.K;
+
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(p.A, (size_t)p.M * K * 2);
+  const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(p.B, (size_t)p.N * K * 2);
+
+  // piece q = i*NW + wave ; rows 16q .. 16q+15 of the stacked [A rows ; B rows] stage image
+  unsigned voff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (i * NW + wave) * 16 + (lane >> 2);
+    const int g4 = (0x1320 >> (((row >> 2) & 3) * 4)) & 3;     // g = {0,2,3,1}
+    const int logical = (lane & 3) ^ g4;
+    const int grow = (i < A_ITERS) ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);  // clamp: never stored
+    voff[i] = (unsigned)grow * (unsigned)(K * 2) + logical * 16;
+  }
+#define STAGE(kt_, slot_)                                                                                   \
+  do {                                                                                                      \
+    char* base_ = smem + (slot_) * STAGE_BYTES + wave * 1024;                                               \
+    const int soff_ = (kt_) * (KS * 2);                                                                     \
+    _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                       \
+      buf_glds16(i < A_ITERS ? rsrcA : rsrcB, base_ + i * NW * 1024, voff[i], soff_);                        \
+    }                                                                                                       \
+  } while (0)
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read: row = 16t + (lane&15), chunk = lane>>4, swizzled with g[(row>>2)&3] (tile offsets are multiples of 16 rows)
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + ((((lane >> 4) ^ ((0x1320 >> (((fr >> 2) & 3) * 4)) & 3)) & 3) << 4);
+  const int a_off = wm * WTM * 64 + frag_off;
+  const int b_off = BM * 64 + wn * WTN * 64 + frag_off;
+
+  const int nkt = K / KS;
+  STAGE(0, 0);
+  if (nkt > 1) STAGE(1, 1);
+  int slot = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tile kt has landed once at most the PPW loads of tile kt+1 are still outstanding
+    if (kt + 1 < nkt) {
+      static_assert(PPW == 6 || PPW == 4 || PPW == 8, "add a vmcnt literal for this piece count");
+      if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // publishes tile kt; everyone is done reading slot (kt+2)%3 = slot of tile kt-1
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nkt) STAGE(kt + 2, slot == 0 ? 2 : slot - 1);
+    const char* buf = smem + slot * STAGE_BYTES;
+    bf16x8 af[MT], bfr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(buf + b_off + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(buf + a_off + i * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+#undef STAGE
+  gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+int launch_ring(const GemmNtArgs& p, hipStream_t stream) {
+  constexpr int lds = 3 * (BM + BN) * 64;
+  auto kern = gemm_nt_ring_kernel<BM, BN, WM, WN, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return VITAMD_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Main kernel: 256x256 tile, 8 waves (2x4, wave tile 128x64), BK = 64, two LDS buffers (128 KiB).
+// The K-tile is cut into 8 groups of 8 MFMAs (one A row-pair x four B fragments x one 32-deep
+// k-substep).  Each group FIRST issues its share of the next tile's LDS-DMA (one 1-KiB piece) and
+// the ds_reads of the NEXT group's fragments, THEN runs its 8 MFMAs, so VMEM issue, LDS latency
+// and matrix work overlap inside one wave instead of arriving in bursts behind the barrier
+// (PMC on the burst form: MFMA pipe 38 % busy, waves 49 % issue-stalled; profiles/r01).
+template <int EPI, int ABL = 0>   // ABL: timing-only ablations (1 = no MFMA, 2 = no LDS-DMA, 3 = no ds_read); results are garbage
+__global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int WTM = 128, WTN = 64, MT = 8, NT = 4;
+  constexpr int PPW = 8;                       // 1-KiB pieces (8 rows x 128 B) per wave per K-tile
+  constexpr int BUF_BYTES = (BM + BN) * 128;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int K = p.K;
+
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(p.A, (size_t)p.M * K * 2);
+  const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(p.B, (size_t)p.N * K * 2);
+  // piece q = i*8 + wave: i < 4 -> A rows, i >= 4 -> B rows (stacked [A;B] stage image, 128-B rows)
+  unsigned voff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ (row & 7);
+    const int grow = (i < 4) ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);
+    voff[i] = (unsigned)grow * (unsigned)(K * 2) + logical * 16;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7)) & 7) << 4);
+  const int a_off = wm * WTM * 128 + frag_off;
+  const int b_off = BM * 128 + wn * WTN * 128 + frag_off;
+  const int nkt = K / 64;
+
+  {  // prologue: whole tile 0
+    char* base = smem + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) buf_glds16(i < 4 ? rsrcA : rsrcB, base + i * NW * 1024, voff[i], 0);
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // tile kt visible; buffer cur^1 free
+    asm volatile("" ::: "memory");
+    const char* buf = smem + cur * BUF_BYTES;
+    char* nbase = smem + (cur ^ 1) * BUF_BYTES + wave * 1024;
+    const bool more = kt + 1 < nkt;
+    const int soff = (kt + 1) * 128;
+
+    bf16x8 bq[2][NT], aq[2][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) if (ABL != 3 || kt == 0) bq[0][j] = *(const bf16x8*)(buf + b_off + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) if (ABL != 3 || kt == 0) aq[0][i] = *(const bf16x8*)(buf + a_off + i * 2048);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int ks = g >> 2, pr = g & 3;
+      if (more && ABL != 2) buf_glds16(g < 4 ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
+      if (g < 7) {
+        const int ks2 = (g + 1) >> 2, pr2 = (g + 1) & 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (ABL != 3 || kt == 0) aq[(g + 1) & 1][i] = *(const bf16x8*)(buf + ((a_off + (2 * pr2 + i) * 2048) ^ (ks2 * 64)));
+      }
+      if (g == 1) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) if (ABL != 3 || kt == 0) bq[1][j] = *(const bf16x8*)(buf + ((b_off + j * 2048) ^ 64));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if constexpr (ABL == 1) { asm volatile("" ::"v"(bq[ks][j]), "v"(aq[g & 1][i])); }
+          else acc[2 * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[g & 1][i], acc[2 * pr + i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+template <int EPI, int ABL = 0>
+int launch_pipe(const GemmNtArgs& p, hipStream_t stream) {
+  constexpr int lds = 2 * 512 * 128;
+  auto kern = gemm_nt_pipe_kernel<EPI, ABL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return VITAMD_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deep-prefetch variant of the 256x256 kernel: BK = 32 stages of 32 KiB in an NS-deep LDS ring
+// (4 -> 128 KiB).  Ablation of the 2-buffer kernel (tools/ablate_gemm.py, profiles/r01) showed the
+// main loop is bound by operand-fetch LATENCY, not MFMA rate: with one K-tile of prefetch distance
+// a tile's slowest 1-KiB piece (an L2 miss, ~2 us under load) gates the whole workgroup every
+// K-step.  Here tile kt+NS-1 is issued while tile kt is computed (NS-1 stages = 96 KiB in flight
+// per CU), behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per 32-deep step.
+template <int EPI, int NS>
+__global__ __launch_bounds__(512) void gemm_nt_deep_kernel(const GemmNtArgs p) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int WTM = 128, WTN = 64, MT = 8, NT = 4;
+  constexpr int PPW = 4;                       // 1-KiB pieces (16 rows x 64 B) per wave per stage
+  constexpr int STAGE_BYTES = (BM + BN) * 64;  // 32 KiB
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int K = p.K;
+
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(p.A, (size_t)p.M * K * 2);
+  const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(p.B, (size_t)p.N * K * 2);
+  // piece q = i*8 + wave: i < 2 -> A rows 16q.., i >= 2 -> B rows (stacked [A;B] image, 64-B rows)
+  unsigned voff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (i * NW + wave) * 16 + (lane >> 2);
+    const int g4 = (0x1320 >> (((row >> 2) & 3) * 4)) & 3;
+    const int logical = (lane & 3) ^ g4;
+    const int grow = (i < 2) ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);
+    voff[i] = (unsigned)grow * (unsigned)(K * 2) + logical * 16;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int frag_off = fr * 64 + ((((lane >> 4) ^ ((0x1320 >> (((fr >> 2) & 3) * 4)) & 3)) & 3) << 4);
+  const int a_off = wm * WTM * 64 + frag_off;
+  const int b_off = BM * 64 + wn * WTN * 64 + frag_off;
+  const int nkt = K / 32;
+
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t) {           // prologue: tiles 0 .. NS-2 (always PPW loads each so
+    char* base = smem + t * STAGE_BYTES + wave * 1024;   // the vmcnt arithmetic below is uniform; past-the-end tiles read clamped, unused bytes)
+    const int kk = min(t, nkt - 1);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) buf_glds16(i < 2 ? rsrcA : rsrcB, base + i * NW * 1024, voff[i], kk * 64);
+  }
+  int slot = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tiles kt+1 .. kt+NS-2 may stay in flight: (NS-2)*PPW outstanding pieces
+    if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (NS == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile kt visible to all; slot of tile kt-1 is free
+    asm volatile("" ::: "memory");
+    const char* buf = smem + slot * STAGE_BYTES;
+    const int nslot = slot == 0 ? NS - 1 : slot - 1;                  // slot of tile kt-1 == slot of tile kt+NS-1
+    char* nbase = smem + nslot * STAGE_BYTES + wave * 1024;
+    const int soff = min(kt + NS - 1, nkt - 1) * 64;                  // tail: harmless re-read of the last tile
+
+    bf16x8 bq[NT], aq[2][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bq[j] = *(const bf16x8*)(buf + b_off + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aq[0][i] = *(const bf16x8*)(buf + a_off + i * 1024);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      buf_glds16(g < 2 ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
+      if (g < 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aq[(g + 1) & 1][i] = *(const bf16x8*)(buf + a_off + (2 * (g + 1) + i) * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[2 * g + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], aq[g & 1][i], acc[2 * g + i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    slot = slot == NS - 1 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail re-reads before LDS is reused / the wave ends
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+template <int EPI, int NS>
+int launch_deep(const GemmNtArgs& p, hipStream_t stream) {
+  constexpr int lds = NS * 512 * 64;
+  auto kern = gemm_nt_deep_kernel<EPI, NS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return VITAMD_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
 int launch(const GemmNtArgs& p, hipStream_t stream) {
   constexpr int lds = 2 * (BM + BN) * 128;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, EPI>;
@@ -226,10 +564,28 @@ int launch(const GemmNtArgs& p, hipStream_t stream) {
 
 template <int EPI>
 int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
-  // tile choice: 256x256 (8 waves) when it yields enough workgroups, else 128x128 (4 waves)
-  const long big = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  // tile selector: 0 = auto, 1 = 256x128 ring kernel (2 workgroups/CU), 256 = 256x256 double-buffered,
+  // 128 = 128x128 double-buffered (small problems; needs K % 64 == 0)
   int tile = p.tile;
-  if (tile == 0) tile = (p.N >= 256 && big >= 192) ? 256 : 128;
+  const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const bool ring_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull;
+  if (tile == 0) {
+    // measured on MI355X (profiles/r01): the grouped-issue pipe kernel wins on long K, the plain
+    // double-buffered kernel on short K (fewer instructions per K-tile); small problems -> 128x128
+    if (p.N >= 256 && big_tiles >= 192 && p.K % 64 == 0) tile = (ring_ok && p.K >= 1536) ? 2 : 256;
+    else tile = (p.K % 64 == 0) ? 128 : 1;
+  }
+  if (tile == 1) return ring_ok ? launch_ring<256, 128, 2, 2, EPI>(p, stream) : VITAMD_ERR_SHAPE;
+  if (tile == 2) return (ring_ok && p.K % 64 == 0) ? launch_pipe<EPI>(p, stream) : VITAMD_ERR_SHAPE;
+  if (tile == 3) return ring_ok ? launch_deep<EPI, 3>(p, stream) : VITAMD_ERR_SHAPE;
+  if (tile == 4) return ring_ok ? launch_deep<EPI, 4>(p, stream) : VITAMD_ERR_SHAPE;
+  if (tile == 5) return ring_ok ? launch_deep<EPI, 5>(p, stream) : VITAMD_ERR_SHAPE;
+  if constexpr (EPI == EPI_BIAS_BF16) {   // timing-only ablations of the pipe kernel (tools/ablate_gemm.py)
+    if (tile == 21) return launch_pipe<EPI, 1>(p, stream);
+    if (tile == 22) return launch_pipe<EPI, 2>(p, stream);
+    if (tile == 23) return launch_pipe<EPI, 3>(p, stream);
+  }
+  if (p.K % BK != 0) return VITAMD_ERR_SHAPE;
   if (tile == 256) return launch<256, 256, 2, 4, EPI>(p, stream);
   return launch<128, 128, 2, 2, EPI>(p, stream);
 }
@@ -237,7 +593,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
 }  // namespace
 
 int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % BK != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
   if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
   switch (p.epi) {
     case EPI_BIAS_BF16: return dispatch_tile<EPI_BIAS_BF16>(p, stream);

@@ -77,18 +77,40 @@ __global__ __launch_bounds__(256) void im2col_generic_kernel(const float* __rest
   }
 }
 
-// colsum[n] += sum_m X[m,n]  (X bf16 [M, ld]); each block owns a row slab, one shaped atomic per column
+// colsum[n] += sum_m X[m,n]  (X bf16 [M, ld]).  16-B loads: a thread owns 8 columns and every 8th
+// row of its block's row slab; the 8 row-groups of a block are combined through LDS, then one
+// shaped atomic per column.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ x, float* __restrict__ out, int M, int N, int ld, int rows_per_block) {
+  __shared__ float red[8][32 * 8];
+  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;       // 32 column groups x 8 row groups
+  const int n = (blockIdx.x * 32 + cg) * 8;
   const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
-  const int n = (blockIdx.x * 256 + threadIdx.x) * 2;  // two columns per thread (4-B loads)
-  if (n >= N) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int m = m_lo; m < m_hi; ++m) {
-    const unsigned int v = *(const unsigned int*)(x + (size_t)m * ld + n);
-    s0 += bf16lo(v); s1 += bf16hi(v);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    for (int m = m_lo + rg; m < m_hi; m += 8) {
+      const u32x4 v = *(const u32x4*)(x + (size_t)m * ld + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[2 * j] += bf16lo(v[j]); s[2 * j + 1] += bf16hi(v[j]); }
+    }
   }
-  atomicAdd(out + n, s0);
-  if (n + 1 < N) atomicAdd(out + n + 1, s1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rg][cg * 8 + j] = s[j];
+  __syncthreads();
+  const int c = threadIdx.x;
+  float t = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) t += red[r][c];
+  const int nn = blockIdx.x * 256 + c;
+  if (nn < N) atomicAdd(out + nn, t);
+}
+
+__global__ __launch_bounds__(256) void colsum_bf16_generic_kernel(const __bf16* __restrict__ x, float* __restrict__ out, int M, int N, int ld, int rows_per_block) {
+  const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = m_lo; m < m_hi; ++m) s += bf2f(x[(size_t)m * ld + n]);
+  atomicAdd(out + n, s);
 }
 
 // Patch-embed backward reduction over the batch (reference train_vit.py:41-44 backward):
@@ -98,12 +120,13 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
 //   dbias[n] += sum_{b,p} bf16(g[b, extra+p, n])
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, float* __restrict__ dpos,
                                                         float* __restrict__ dextra, __bf16* __restrict__ dyp,
-                                                        float* __restrict__ dbias, int B, int seq, int extra, int D) {
+                                                        float* __restrict__ dbias, int B, int seq, int extra, int D, int bchunk) {
   const int t = blockIdx.x;  // token position
+  const int b_lo = blockIdx.y * bchunk, b_hi = min(B, b_lo + bchunk);
   const int np = seq - extra;
   for (int c = threadIdx.x; c < D; c += 256) {
     float s = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = b_lo; b < b_hi; ++b) {
       const float v = g[((size_t)b * seq + t) * D + c];
       s += v;
       if (t >= extra) {
@@ -112,9 +135,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         sb += bf2f(vb);
       }
     }
-    if (t < extra) dextra[(size_t)t * D + c] = s;
+    if (t < extra) atomicAdd(dextra + (size_t)t * D + c, s);   // outputs are zeroed by the caller
     else {
-      dpos[(size_t)(t - extra) * D + c] = s;
+      atomicAdd(dpos + (size_t)(t - extra) * D + c, s);
       atomicAdd(dbias + c, sb);
     }
   }
@@ -155,13 +178,16 @@ extern "C" int vitamd_im2col_bf16(const float* img, void* out_bf16, int B, int C
 }
 
 extern "C" int vitamd_colsum_bf16(const void* x_bf16, float* out, int M, int N, int ld, void* stream) {
-  if (M <= 0 || N <= 0 || ld < N || (ld & 1)) return VITAMD_ERR_SHAPE;
+  if (M <= 0 || N <= 0 || ld < N) return VITAMD_ERR_SHAPE;
   if (!x_bf16 || !out) return VITAMD_ERR_ARG;
-  const int gx = (N + 511) / 512;
-  int gy = 1024 / gx; if (gy < 1) gy = 1;
-  int rpb = (M + gy - 1) / gy; if (rpb < 16) rpb = 16;
+  const int gx = (N + 255) / 256;
+  int gy = 2048 / gx; if (gy < 1) gy = 1;
+  int rpb = (M + gy - 1) / gy; if (rpb < 64) rpb = 64;
   gy = (M + rpb - 1) / rpb;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_bf16, out, M, N, ld, rpb);
+  if (N % 8 == 0 && ld % 8 == 0)
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_bf16, out, M, N, ld, rpb);
+  else
+    hipLaunchKernelGGL(colsum_bf16_generic_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_bf16, out, M, N, ld, rpb);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
@@ -169,6 +195,7 @@ extern "C" int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void
                                 int extra, int D, void* stream) {
   if (B <= 0 || seq <= 0 || extra < 0 || extra > seq || D <= 0) return VITAMD_ERR_SHAPE;
   if (!g || (seq > extra && (!dpos || !dyp_bf16 || !dbias)) || (extra > 0 && !dextra)) return VITAMD_ERR_ARG;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(seq), dim3(256), 0, (hipStream_t)stream, g, dpos, dextra, (__bf16*)dyp_bf16, dbias, B, seq, extra, D);
+  const int bchunk = 8;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(seq, (B + bchunk - 1) / bchunk), dim3(256), 0, (hipStream_t)stream, g, dpos, dextra, (__bf16*)dyp_bf16, dbias, B, seq, extra, D, bchunk);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

@@ -67,36 +67,101 @@ def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad):
     return x2, saved
 
 
-def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, dy2=None, db2=None, emit_bf16=False, emit_colsum=None):
-    """g2 fp32 [M,D] = dL/dx2.  Returns g0 and the six parameter gradients (fp32).
-    dy2/db2: bf16(g2) and its column sums if a previous kernel already produced them.
-    emit_bf16/emit_colsum: also return bf16(g0) (+ accumulate its column sums) for the layer below."""
+class _Side:
+    """A second HIP stream for the weight-gradient GEMMs and bias-gradient column sums.  They
+    depend on the input-gradient chain but nothing in that chain depends on them, so running them
+    beside it lets their workgroups fill the CUs a GEMM's last partial round leaves idle (e.g.
+    591 tiles on 256 CUs = 2.31 rounds) and hides each kernel's prologue/epilogue under the other."""
+
+    def __init__(self):
+        self._streams = {}
+        self.enabled = True
+
+    def stream(self, device):
+        s = self._streams.get(device)
+        if s is None:
+            s = self._streams[device] = torch.cuda.Stream(device=device)
+        return s
+
+
+SIDE = _Side()
+
+
+def grad_arena(D, n_layers, device):
+    """One zero-filled fp32 buffer for every parameter gradient of `n_layers` layers (one memset
+    instead of 6 per layer); returns per-layer (dWqkv, dbqkv, dW1, db1, dW2, db2) views."""
+    sizes = (3 * D * D, 3 * D, 4 * D * D, 4 * D, 4 * D * D, D)
+    shapes = ((3 * D, D), (3 * D,), (4 * D, D), (4 * D,), (D, 4 * D), (D,))
+    per = sum(sizes)
+    flat = torch.zeros(per * n_layers, dtype=F32, device=device)
+    out = []
+    for i in range(n_layers):
+        off, views = i * per, []
+        for n, sh in zip(sizes, shapes):
+            views.append(flat[off: off + n].view(sh))
+            off += n
+        out.append(tuple(views))
+    return out
+
+
+def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, have_db2=False, emit_bf16=False,
+                   emit_colsum=None):
+    """g2 fp32 [M,D] = dL/dx2.  Fills `grads` = (dWqkv, dbqkv, dW1, db1, dW2, db2) (zero-initialised
+    fp32, accumulated into) and returns (g0, bf16(g0) or None).
+    dy2: bf16(g2) if a previous kernel already produced it (then db2 is already in grads[5] when
+    have_db2).  emit_bf16/emit_colsum: also produce bf16(g0) and add its column sums to emit_colsum
+    (the fc2 bias gradient of the layer below)."""
     x0, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, bln, pre, h = saved
-    dev = g2.device
-    D = x0.shape[1]
+    dWqkv, dbqkv, dW1, db1, dW2, db2 = grads
+    main = torch.cuda.current_stream()
+    side = SIDE.stream(g2.device) if SIDE.enabled else main
+
+    def on_side(fn, *tensors):
+        """run fn on the side stream after everything enqueued so far on the main stream"""
+        if side is main:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            t.record_stream(side)   # keep the allocator from recycling them under the side stream
+
     _, wqkv_t = WEIGHTS.get(wqkv, True)
     _, w1_t = WEIGHTS.get(w1, True)
     _, w2_t = WEIGHTS.get(w2, True)
     if dy2 is None:
         dy2 = ops.cast_bf16(g2)
-        db2 = ops.colsum(dy2)
     # ---- MLP
-    dW2 = torch.zeros((D, 4 * D), dtype=F32, device=dev)
-    ops.gemm_tn(dy2, h, dW2)
-    db1 = torch.zeros((4 * D,), dtype=F32, device=dev)
+    def wgrad_fc2():
+        ops.gemm_tn(dy2, h, dW2)
+        if not have_db2:
+            ops.colsum(dy2, db2)
+    on_side(wgrad_fc2, dy2, h, dW2, db2)
     dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)            # dgrad fc2 . gelu'
-    dW1 = torch.zeros((4 * D, D), dtype=F32, device=dev)
-    ops.gemm_tn(dpre, bln, dW1)
+    on_side(lambda: ops.gemm_tn(dpre, bln, dW1), dpre, bln, dW1)
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True)
     # ---- attention
     dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal)
-    dbqkv = ops.colsum(dqkv)
-    dWqkv = torch.zeros((3 * D, D), dtype=F32, device=dev)
-    ops.gemm_tn(dqkv, a, dWqkv)
+
+    def wgrad_qkv():
+        ops.gemm_tn(dqkv, a, dWqkv)
+        ops.colsum(dqkv, dbqkv)
+    on_side(wgrad_qkv, dqkv, a, dWqkv, dbqkv)
     da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
     g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum)
-    return g0, g0b, (dWqkv, dbqkv, dW1, db1, dW2, db2)
+    return g0, g0b
+
+
+def join_side(device):
+    """main stream waits for everything enqueued on the side stream"""
+    if SIDE.enabled:
+        ev = torch.cuda.Event()
+        ev.record(SIDE.stream(device))
+        torch.cuda.current_stream().wait_event(ev)
 
 
 class TransformerLayerFn(torch.autograd.Function):
@@ -116,9 +181,10 @@ class TransformerLayerFn(torch.autograd.Function):
     def backward(ctx, g):
         B, N, D, H, causal, xdtype = ctx.meta
         wqkv, w1, w2 = ctx.weights
-        g0, _, (dWqkv, dbqkv, dW1, db1, dW2, db2) = layer_backward(_f32c(g).view(B * N, D), ctx.saved_tensors, wqkv, w1, w2,
-                                                                   B, N, H, causal)
-        return g0.view(B, N, D).to(xdtype), dWqkv, dbqkv, dW1, db1, dW2, db2, None, None
+        (grads,) = grad_arena(D, 1, g.device)
+        g0, _ = layer_backward(_f32c(g).view(B * N, D), ctx.saved_tensors, wqkv, w1, w2, B, N, H, causal, grads)
+        join_side(g.device)
+        return (g0.view(B, N, D).to(xdtype), *grads, None, None)
 
 
 class TransformerStackFn(torch.autograd.Function):
@@ -151,15 +217,15 @@ class TransformerStackFn(torch.autograd.Function):
         params = ctx.params
         n_saved = len(saved_all) // L
         cur = _f32c(g).view(B * N, D)
-        grads = [None] * (6 * L)
-        dy2, db2 = None, None
+        arena = grad_arena(D, L, cur.device)
+        dy2 = None
         for i in reversed(range(L)):
             wqkv, _, w1, _, w2, _ = params[6 * i: 6 * i + 6]
-            nxt_db2 = torch.zeros((D,), dtype=F32, device=cur.device) if i > 0 else None
-            cur, g0b, pg = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal,
-                                          dy2=dy2, db2=db2, emit_bf16=i > 0, emit_colsum=nxt_db2)
-            grads[6 * i: 6 * i + 6] = pg
-            dy2, db2 = g0b, nxt_db2
+            nxt_db2 = arena[i - 1][5] if i > 0 else None      # layer i's first LN backward feeds layer i-1's fc2 bias grad
+            cur, dy2 = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal, arena[i],
+                                      dy2=dy2, have_db2=dy2 is not None, emit_bf16=i > 0, emit_colsum=nxt_db2)
+        join_side(cur.device)
+        grads = [t for layer in arena for t in layer]
         return (cur.view(B, N, D).to(xdtype), None, None, *grads)
 
 

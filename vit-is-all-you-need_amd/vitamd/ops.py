@@ -166,8 +166,8 @@ def embed_bwd(g, B, seq, extra, D):
     _need(g, F32, "g", 2)
     n_p = seq - extra
     dev = g.device
-    dpos = torch.empty((n_p, D), dtype=F32, device=dev)
-    dextra = torch.empty((extra, D), dtype=F32, device=dev)
+    dpos = torch.zeros((n_p, D), dtype=F32, device=dev)
+    dextra = torch.zeros((extra, D), dtype=F32, device=dev)
     dyp = torch.empty((B * n_p, D), dtype=BF16, device=dev)
     dbias = torch.zeros((D,), dtype=F32, device=dev)
     _lib.check(_L().vitamd_embed_bwd(_p(g), _p(dpos), _p(dextra) if extra > 0 else None, _p(dyp), _p(dbias), B, seq, extra, D,
