@@ -5,10 +5,15 @@
 
 extern "C" int vitamd_abi_version(void) { return 1; }
 
+int g_vitamd_debug = 0;
+// timing-only ablation knob for tools/ablate_*.py (bit 0: skip GELU math, bit 1: skip the second store,
+// bit 2: skip the epilogue loads).  Results are wrong when non-zero.  Not part of the public header.
+extern "C" int vitamd_set_debug(int bits) { g_vitamd_debug = bits; return 0; }
+
 extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
                                    float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
                                    int tile, void* stream) {
-  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile};
+  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug};
   if (!(tile >= 0 && tile <= 5) && tile != 128 && tile != 256 && (tile < 21 || tile > 23)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }

@@ -59,14 +59,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pre[r] = round_bf16(v[r]);
-          act[r] = gelu_fwd(pre[r]);
+          act[r] = (p.dbg & 1) ? pre[r] : gelu_fwd(pre[r]);
         }
         u32x2 o1 = {pack_bf16x2(pre[0], pre[1]), pack_bf16x2(pre[2], pre[3])};
         u32x2 o2 = {pack_bf16x2(act[0], act[1]), pack_bf16x2(act[2], act[3])};
         *(u32x2*)((__bf16*)p.out + (size_t)m * ldo + n) = o1;
-        *(u32x2*)((__bf16*)p.out2 + (size_t)m * ldo + n) = o2;
+        if (!(p.dbg & 2)) *(u32x2*)((__bf16*)p.out2 + (size_t)m * ldo + n) = o2;
       } else if constexpr (EPI == EPI_RESID_F32) {
-        const f32x4 res = *(const f32x4*)((const float*)p.aux + (size_t)m * ldo + n);
+        const f32x4 res = (p.dbg & 4) ? v : *(const f32x4*)((const float*)p.aux + (size_t)m * ldo + n);
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = res[r] + round_bf16(v[r]);
@@ -124,6 +124,151 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) s += red[w * BN + c];
+        if (n0 + c < p.N) atomicAdd(p.colsum + n0 + c, s);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-major epilogue for the 128x64 wave tile (8 waves, 256x256 block).  In the accumulator layout
+// a lane owns 4 columns of 16 different rows, so direct stores are 8-B pieces scattered over 16 rows:
+// the epilogue was store/load-ISSUE bound (tools/ablate_epilogue.py: the second GELU output cost
+// 160 us, the residual read 148 us, the erf math 7 us).  Here each wave transposes its tile through
+// a private 16-KiB LDS image ([128 rows][64 bf16], 16-B chunk index XOR (row&7)), after which a lane
+// owns 8 consecutive columns of one row: every global access is 16 B per lane and a wave-instruction
+// covers whole 128-B (bf16) / 256-B (fp32) row segments of 8 rows.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn,
+                                                   int lane, int tid, int wave, char* smem) {
+  constexpr int BN = 256;
+  __syncthreads();                       // every wave is done reading the operand buffers
+  char* tile = smem + wave * 16384;      // wave-private image
+  const int mloc = lane & 15, g = lane >> 4;
+  const int ncol_acc = n0 + wn * 64 + 4 * g;
+  // ---- 1. bias (+ bf16 rounding of the Linear output) in the accumulator layout, pack, write to LDS
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI != EPI_DGELU) {
+      const int n = ncol_acc + j * 16;
+      if (p.bias && n < p.N) {
+        const f32x4 b = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[r] = round_bf16(b[r]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 v = acc[i][j] + bias4;
+      const int row = 16 * i + mloc;
+      const int chunk = (2 * j + (g >> 1)) ^ (row & 7);
+      u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *(u32x2*)(tile + row * 128 + (chunk << 4) + (g & 1) * 8) = o;
+    }
+  }
+  // ---- 2. read back row-major: lane -> row (lane>>3) + 8*it, physical chunk lane&7
+  const int rsub = lane >> 3, pc = lane & 7;
+  const int ldo = p.ldo;
+  float cs[8];
+  if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cs[c] = 0.f;
+  }
+  // the logical chunk of (row, pc) is pc ^ (row&7) and row&7 == rsub for every it (rows step by 8)
+  const int n = n0 + wn * 64 + 8 * (pc ^ rsub);
+  const bool ncol_ok = n < p.N;           // N % 8 == 0 is required by the row epilogue
+  const int nc = ncol_ok ? n : 0;
+  const int mbase = m0 + wm * 128 + rsub;
+  // ---- 2a. the accumulators are dead now: issue EVERY auxiliary load of the tile up front (clamped
+  // rows, unconditional) so their latency overlaps the LDS round trip instead of serialising per row
+  u32x4 auxb[EPI == EPI_DGELU ? 16 : 1];
+  f32x4 auxf[(EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) ? 32 : 1];
+  if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int m = min(mbase + 8 * it, p.M - 1);
+      auxb[it] = *(const u32x4*)((const __bf16*)p.aux + (size_t)m * ldo + nc);
+    }
+  } else if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int m = min(mbase + 8 * it, p.M - 1);
+      const float* rp = (const float*)p.aux + (size_t)m * ldo + nc;
+      auxf[2 * it] = *(const f32x4*)rp;
+      auxf[2 * it + 1] = *(const f32x4*)(rp + 4);
+    }
+  } else if constexpr (EPI == EPI_PATCH_F32) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int m = min(mbase + 8 * it, p.M - 1);
+      const float* pp = (const float*)p.aux + (size_t)(m % p.n_patches) * ldo + nc;
+      auxf[2 * it] = *(const f32x4*)pp;
+      auxf[2 * it + 1] = *(const f32x4*)(pp + 4);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int rloc = rsub + 8 * it;
+    const int m = mbase + 8 * it;
+    const u32x4 v = *(const u32x4*)(tile + rloc * 128 + pc * 16);
+    const bool ok = m < p.M && ncol_ok;
+    if constexpr (EPI == EPI_BIAS_BF16) {
+      if (ok) *(u32x4*)((__bf16*)p.out + (size_t)m * ldo + n) = v;
+    } else if constexpr (EPI == EPI_GELU) {
+      u32x4 a;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = pack_bf16x2(gelu_fwd(bf16lo(v[c])), gelu_fwd(bf16hi(v[c])));
+      if (ok) {
+        *(u32x4*)((__bf16*)p.out + (size_t)m * ldo + n) = v;
+        *(u32x4*)((__bf16*)p.out2 + (size_t)m * ldo + n) = a;
+      }
+    } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) {
+      const f32x4 r0 = auxf[2 * it], r1 = auxf[2 * it + 1];
+      f32x4 o0 = {r0[0] + bf16lo(v[0]), r0[1] + bf16hi(v[0]), r0[2] + bf16lo(v[1]), r0[3] + bf16hi(v[1])};
+      f32x4 o1 = {r1[0] + bf16lo(v[2]), r1[1] + bf16hi(v[2]), r1[2] + bf16lo(v[3]), r1[3] + bf16hi(v[3])};
+      size_t orow = (size_t)m;
+      if constexpr (EPI == EPI_PATCH_F32) {
+        const int b = m / p.n_patches, pidx = m - b * p.n_patches;
+        orow = (size_t)b * p.seq + p.extra + pidx;
+      }
+      if (ok) {
+        float* op = (float*)p.out + orow * ldo + n;
+        *(f32x4*)op = o0;
+        *(f32x4*)(op + 4) = o1;
+      }
+    } else if constexpr (EPI == EPI_DGELU) {
+      const u32x4 pz = auxb[it];
+      u32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float lo = round_bf16(bf16lo(v[c]) * gelu_grad(bf16lo(pz[c])));
+        const float hi = round_bf16(bf16hi(v[c]) * gelu_grad(bf16hi(pz[c])));
+        if (ok) { cs[2 * c] += lo; cs[2 * c + 1] += hi; }
+        o[c] = pack_bf16x2(lo, hi);
+      }
+      if (ok) *(u32x4*)((__bf16*)p.out + (size_t)m * ldo + n) = o;
+    }
+  }
+  if constexpr (EPI == EPI_DGELU) {
+    if (p.colsum) {
+      // lanes with equal (pc, rsub) parity... every lane's 8 columns are fixed: reduce over the 8 lanes that
+      // share pc ^ rsub?  No: column block = pc ^ rsub, so lanes (pc, rsub) and (pc', rsub') share columns
+      // iff pc^rsub == pc'^rsub'.  Combine through LDS: red[wave][col] += with shaped accesses.
+      __syncthreads();                   // all waves finished reading their images
+      float* red = (float*)smem;         // [8 waves][8 rsub][64 cols] floats = 16 KiB
+      float* mine = red + (wave * 8 + rsub) * 64 + 8 * (pc ^ rsub);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) mine[c] = cs[c];
+      __syncthreads();
+      // column c of the block: waves with wn == c/64 (two of them: wm = 0,1), 8 rsub rows each
+      for (int c = tid; c < BN; c += 512) {
+        const int wnn = c >> 6, cc = c & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) s += red[((w * 4 + wnn) * 8 + r) * 64 + cc];
         if (n0 + c < p.N) atomicAdd(p.colsum + n0 + c, s);
       }
     }
@@ -211,6 +356,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const GemmNtArgs 
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 4 && EPI != EPI_F32) {
+    if (p.N % 8 == 0 && p.ldo % 8 == 0) {
+      gemm_epilogue_rows<EPI>(p, acc, m0, n0, wm, wn, lane, tid, wave, smem);
+      return;
     }
   }
   gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
@@ -420,7 +571,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+  if constexpr (EPI == EPI_F32) gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+  else if (p.N % 8 == 0 && p.ldo % 8 == 0) gemm_epilogue_rows<EPI>(p, acc, m0, n0, wm, wn, lane, tid, wave, smem);
+  else gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
 template <int EPI, int ABL = 0>
@@ -570,9 +723,8 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool ring_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull;
   if (tile == 0) {
-    // measured on MI355X (profiles/r01): the grouped-issue pipe kernel wins on long K, the plain
-    // double-buffered kernel on short K (fewer instructions per K-tile); small problems -> 128x128
-    if (p.N >= 256 && big_tiles >= 192 && p.K % 64 == 0) tile = (ring_ok && p.K >= 1536) ? 2 : 256;
+    // the grouped-issue pipe kernel is the default for big problems; small problems -> 128x128
+    if (p.N >= 256 && big_tiles >= 192 && p.K % 64 == 0) tile = ring_ok ? 2 : 256;
     else tile = (p.K % 64 == 0) ? 128 : 1;
   }
   if (tile == 1) return ring_ok ? launch_ring<256, 128, 2, 2, EPI>(p, stream) : VITAMD_ERR_SHAPE;

@@ -23,6 +23,7 @@ struct GemmNtArgs {
   int epi;
   int n_patches, seq, extra;  // EPI_PATCH_F32 row remap
   int tile;                   // 0 = auto, 128, 256
+  int dbg;                    // timing-only ablation bits (vitamd_set_debug); 0 in production
 };
 
 struct GemmTnArgs {
@@ -33,5 +34,6 @@ struct GemmTnArgs {
   int splits;      // 0 = auto
 };
 
+extern int g_vitamd_debug;
 int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream);
 int vitamd_gemm_tn_impl(const GemmTnArgs& p, hipStream_t stream);
