@@ -78,6 +78,12 @@ __device__ __forceinline__ void load_lane_frags(const __bf16* __restrict__ g, in
 }
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32 (inputs <= 0 or masked)
+__device__ __forceinline__ float max16(const f32x16& v) {
+  float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), b = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
+  float c = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), d = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
 
 // store a transposed 64x32 accumulator pair  acc[dt][reg] = X^T[d][row]  as X[row][d] bf16, scaled
 __device__ __forceinline__ void store_rows_T(__bf16* __restrict__ g, int ld, int N, int r0, int lane, const f32x16 (&acc)[2], float scale) {
@@ -92,6 +98,30 @@ __device__ __forceinline__ void store_rows_T(__bf16* __restrict__ g, int ld, int
                  pack_bf16x2(acc[dt][4 * u + 2] * scale, acc[dt][4 * u + 3] * scale)};
       *(u32x2*)(p + 32 * dt + 8 * u) = o;
     }
+}
+
+// Same, but transposed through a wave-private 4-KiB LDS image first so that every lane stores 16 B
+// and a wave-instruction covers 8 whole 128-B head rows (4 store instructions instead of 16
+// scattered 8-B ones: the output tail was store-issue bound).
+__device__ __forceinline__ void store_rows_T_lds(__bf16* __restrict__ g, int ld, int N, int r0, int lane, const f32x16 (&acc)[2],
+                                                 float scale, char* img) {
+  const int rr = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      u32x2 o = {pack_bf16x2(acc[dt][4 * u] * scale, acc[dt][4 * u + 1] * scale),
+                 pack_bf16x2(acc[dt][4 * u + 2] * scale, acc[dt][4 * u + 3] * scale)};
+      // element columns 32dt + 8u + 4h .. +3  -> 16-B chunk 4dt + u, half h ; chunk XOR (row & 7)
+      *(u32x2*)(img + rr * 128 + (((4 * dt + u) ^ (rr & 7)) << 4) + h * 8) = o;
+    }
+  // wave-private image: the same wave reads it back (the compiler orders LDS accesses of one wave)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (lane >> 3) + 8 * it, pc = lane & 7;
+    const u32x4 v = *(const u32x4*)(img + row * 128 + pc * 16);
+    if (r0 + row < N) *(u32x4*)(g + (size_t)(r0 + row) * ld + 8 * (pc ^ (row & 7))) = v;
+  }
 }
 
 struct AttnArgs {
@@ -141,22 +171,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s, 0, 0, 0);
-      float tmax = NEG_BIG;
+      if (32 * T + 32 > N || (a.causal && T == qb)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * T + acc_row(r, lane);
-        const bool ok = key < N && (!a.causal || key <= qrow);
-        s[r] = ok ? s[r] * c : NEG_BIG;
-        tmax = fmaxf(tmax, s[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * T + acc_row(r, lane);
+          if (!(key < N && (!a.causal || key <= qrow))) s[r] = NEG_BIG;
+        }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      float tmax = max16(s);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
       const float mnew = fmaxf(m, tmax);
-      const float alpha = exp2f(m - mnew);
+      const float alpha = fast_exp2(m - mnew);
       m = mnew;
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = exp2f(s[r] - mnew);
+        s[r] = fast_exp2(__builtin_fmaf(s[r], c, -mnew));
         psum += s[r];
       }
       l = l * alpha + psum;
@@ -179,8 +209,88 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ forward, N <= 256
+// The whole score row of a query fits in registers (NKT tiles x 16 fp32), so there is no online
+// rescaling: S for every key tile, one row maximum, exp2, then P.V.  Per element the VALU work is
+// fma + v_exp + add + cvt (the kernel is VALU-bound at dh = 64, not MFMA-bound).
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  constexpr int nt = NKT, npad = NKT * 32;
+  char* ktile = smem;
+  char* vtile = smem + npad * 128;
+  char* oimg = smem + 2 * npad * 128 + wave * 4096;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  stage_tile(qbase + D, D3, N, npad, ktile, wave, lane);
+  stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float c = a.scale_log2e;
+  const int wrot = (wave + blockIdx.x) & 3;   // rotate which wave gets the short list of query blocks
+  for (int qb = wrot; qb < nt; qb += 4) {
+    const int q0 = qb * 32;
+    const int qrow = q0 + (lane & 31);
+    bf16x8 qf[4];
+    load_lane_frags(qbase, D3, N, q0, lane, qf);
+    const int t_end = a.causal ? qb + 1 : nt;
+    f32x16 s[NKT];
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      if (T < t_end) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[T][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s[T], 0, 0, 0);
+        if (32 * T + 32 > N || (a.causal && T == qb)) {   // only boundary tiles need masking (wave-uniform)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = 32 * T + acc_row(r, lane);
+            if (!(key < N && (!a.causal || key <= qrow))) s[T][r] = NEG_BIG;
+          }
+        }
+        mx = fmaxf(mx, max16(s[T]));
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * c;
+    float l = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      if (T < t_end) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pexp = fast_exp2(__builtin_fmaf(s[T][r], c, -mc));
+          l += pexp;
+          s[T][r] = pexp;
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const bf16x8 pf = acc_to_frag(s[T], sidx);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vtile, T, sidx, dt, lane), pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    store_rows_T_lds(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg);
+    if (lane < 32 && qrow < N) a.lse2[((size_t)b * a.H + hh) * N + qrow] = mc + log2f(l);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward, dQ
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
@@ -188,6 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   const int nt = (N + 31) / 32, npad = nt * 32;
   char* ktile = smem;
   char* vtile = smem + npad * 128;
+  char* oimg = smem + 2 * npad * 128 + wave * 4096;
   const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
   stage_tile(qbase + D, D3, N, npad, ktile, wave, lane);
   stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane);
@@ -197,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   const float c = a.scale_log2e;
   const __bf16* obase = a.o + (size_t)b * N * D + hh * DH;
   const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
-  for (int qb = wave; qb < nt; qb += 4) {
+  for (int qb = (wave + blockIdx.x) & 3; qb < nt; qb += 4) {
     const int q0 = qb * 32;
     const int qrow = q0 + (lane & 31);
     bf16x8 qf[4], dof[4], of[4];
@@ -231,10 +342,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = 32 * T + acc_row(r, lane);
-        const bool ok = key < N && (!a.causal || key <= qrow);
-        const float p = ok ? exp2f(s[r] * c - lse2) : 0.f;
-        s[r] = p * (dp[r] - delta);  // dS^T (the 1/sqrt(dh) factor is applied once at the end)
+        const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
+        s[r] = pexp * (dp[r] - delta);  // dS^T (the 1/sqrt(dh) factor is applied once at the end)
+      }
+      if (32 * T + 32 > N || (a.causal && T == qb)) {   // boundary tiles: zero the masked keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * T + acc_row(r, lane);
+          if (!(key < N && (!a.causal || key <= qrow))) s[r] = 0.f;
+        }
       }
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
@@ -244,12 +360,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ktile, T, sidx, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    store_rows_T(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale);
+    store_rows_T_lds(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale, oimg);
   }
 }
 
 // ------------------------------------------------------------------------------------------ backward, dK and dV
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
@@ -259,6 +375,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   char* dotile = smem + npad * 128;
   float* lse_s = (float*)(smem + 2 * npad * 128);
   float* delta_s = lse_s + npad;
+  char* oimg = smem + 2 * npad * 128 + 2 * npad * 4 + wave * 4096;
   const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
   const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
   stage_tile(qbase, D3, N, npad, qtile, wave, lane);
@@ -272,7 +389,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   __syncthreads();
 
   const float c = a.scale_log2e;
-  for (int kb = wave; kb < nt; kb += 4) {
+  for (int kb = (wave + blockIdx.x) & 3; kb < nt; kb += 4) {
     const int k0 = kb * 32;
     const int krow = k0 + (lane & 31);
     bf16x8 kf[4], vf[4];
@@ -301,11 +418,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         const f32x4 del4 = *(const f32x4*)(delta_s + qr);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = 4 * u + i, query = qr + i;
-          const bool ok = query < N && krow < N && (!a.causal || krow <= query);
-          const float p = ok ? exp2f(s[r] * c - lse4[i]) : 0.f;
-          pmat[r] = p;
-          s[r] = p * (dp[r] - del4[i]);
+          const int r = 4 * u + i;
+          const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse4[i]));
+          pmat[r] = pexp;
+          s[r] = pexp * (dp[r] - del4[i]);
+        }
+        if (32 * T + 32 > N || k0 + 32 > N || (a.causal && T == kb)) {   // boundary tiles only (wave-uniform)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * u + i, query = qr + i;
+            if (!(query < N && krow < N && (!a.causal || krow <= query))) { pmat[r] = 0.f; s[r] = 0.f; }
+          }
         }
       }
 #pragma unroll
@@ -320,8 +443,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
       }
     }
     __bf16* dbase = a.dqkv + (size_t)b * N * D3 + hh * DH;
-    store_rows_T(dbase + D, D3, N, k0, lane, dk, a.scale);
-    store_rows_T(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f);
+    store_rows_T_lds(dbase + D, D3, N, k0, lane, dk, a.scale, oimg);
+    store_rows_T_lds(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f, oimg);
   }
 }
 
@@ -342,9 +465,21 @@ extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B
   AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2) return VITAMD_ERR_ARG;
-  const int npad = (N + 31) / 32 * 32, lds = 2 * npad * 128;
-  if (int e = set_lds(attn_fwd_kernel, lds)) return e;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+  const int nkt = (N + 31) / 32, npad = nkt * 32;
+  if (nkt <= 8) {
+    const int lds = 2 * npad * 128 + 4 * 4096;
+#define FWD_SMALL(K)                                                                                          \
+  case K:                                                                                                     \
+    if (int e = set_lds(attn_fwd_small_kernel<K>, lds)) return e;                                             \
+    hipLaunchKernelGGL(attn_fwd_small_kernel<K>, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);         \
+    break;
+    switch (nkt) { FWD_SMALL(1) FWD_SMALL(2) FWD_SMALL(3) FWD_SMALL(4) FWD_SMALL(5) FWD_SMALL(6) FWD_SMALL(7) FWD_SMALL(8) }
+#undef FWD_SMALL
+  } else {
+    const int lds = 2 * npad * 128;
+    if (int e = set_lds(attn_fwd_kernel, lds)) return e;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+  }
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
@@ -356,7 +491,7 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta) return VITAMD_ERR_ARG;
   const int npad = (N + 31) / 32 * 32;
-  const int lds1 = 2 * npad * 128, lds2 = 2 * npad * 128 + 2 * npad * 4;
+  const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
   if (int e = set_lds(attn_bwd_dq_kernel, lds1)) return e;
   if (int e = set_lds(attn_bwd_dkv_kernel, lds2)) return e;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(256), lds1, (hipStream_t)stream, a);   // also writes delta
