@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "work")
+    __slots__ = ("flat", "params", "offsets", "pending", "work", "launched")
 
     def __init__(self, params, device):
         self.params = params
@@ -31,6 +31,7 @@ class _Bucket:
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.pending = len(params)
         self.work = None
+        self.launched = False
 
     def view(self, i):
         p = self.params[i]
@@ -55,6 +56,25 @@ class DataParallel(torch.nn.Module):
                 dist.broadcast(t.data, src=0, group=process_group)
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets, cur, size = [], [], 0
+        # transformer stacks get one bucket per layer, in the exact (dWqkv, dbqkv, dW1, db1, dW2, db2)
+        # order of the kernels' gradient arena: their backward writes into the bucket directly and
+        # starts the all-reduce per layer (functions.GradSink)
+        self._stack_layers = {}
+        in_stack = set()
+        try:
+            from transformer import Transformer
+            for m in module.modules():
+                if isinstance(m, Transformer) and all(p.requires_grad for p in m.parameters()) and next(m.parameters()).is_cuda:
+                    key = tuple(id(p) for layer in m.layers for p in layer._params())
+                    layer_buckets = []
+                    for layer in m.layers:
+                        lp = list(layer._params())
+                        layer_buckets.append(_Bucket(lp, lp[0].device))
+                        in_stack.update(id(p) for p in lp)
+                    self._stack_layers[key] = layer_buckets
+        except ImportError:
+            pass
+        params = [p for p in params if id(p) not in in_stack]
         for p in reversed(params):  # backward produces gradients roughly in reverse registration order
             if cur and size + p.numel() > cap:
                 self.buckets.append(_Bucket(cur, p.device))
@@ -63,6 +83,11 @@ class DataParallel(torch.nn.Module):
             size += p.numel()
         if cur:
             self.buckets.append(_Bucket(cur, cur[0].device))
+        for lb in self._stack_layers.values():
+            self.buckets.extend(reversed(lb))
+        if self._stack_layers:
+            from . import functions
+            functions.GradSink.sink = self
         self._slot = {}
         for b in self.buckets:
             for i, p in enumerate(b.params):
@@ -72,14 +97,48 @@ class DataParallel(torch.nn.Module):
     def forward(self, *a, **kw):
         return self.module(*a, **kw)
 
+    # ---- gradient sink interface (called from functions.TransformerStackFn.backward) ----
+    def owns(self, params):
+        return tuple(id(p) for p in params) in self._stack_layers
+
+    def arena_for(self, params, n_layers):
+        lb = self._stack_layers.get(tuple(id(p) for p in params))
+        if lb is None or len(lb) != n_layers:
+            return None
+        out = []
+        for b in lb:
+            b.flat.zero_()            # the kernels accumulate (atomics / column sums) into the bucket
+            out.append(tuple(b.view(i) for i in range(6)))
+        return out
+
+    def layer_ready(self, params, i):
+        """every gradient of layer i is enqueued (input-gradient chain on the current stream, weight
+        gradients on the side stream): reduce its bucket on the side stream, behind both"""
+        b = self._stack_layers[tuple(id(p) for p in params)][i]
+        b.launched = True
+        if self.world == 1:
+            return
+        from .functions import SIDE
+        main = torch.cuda.current_stream()
+        side = SIDE.stream(b.flat.device) if SIDE.enabled else main
+        if side is not main:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+        with torch.cuda.stream(side):
+            b.flat.div_(self.world)
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _on_grad(self, p):
         b, i = self._slot[p]
         v = b.view(i)
-        if p.grad.data_ptr() != v.data_ptr():
+        if b.launched:
+            p.grad = v           # already written in place (and possibly already being reduced)
+        elif p.grad.data_ptr() != v.data_ptr():
             v.copy_(p.grad)
             p.grad = v           # the bucket slice IS the gradient from here on
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
+        if b.pending == 0 and self.world > 1 and not b.launched:
             b.flat.div_(self.world)  # pre-divide: sum of shares = mean, works on every backend
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -90,6 +149,7 @@ class DataParallel(torch.nn.Module):
                 b.work.wait()
                 b.work = None
             b.pending = len(b.params)
+            b.launched = False
 
     def zero_grad(self, set_to_none: bool = True):
         # gradients live in the buckets; dropping the references is enough (hooks re-attach views)

@@ -87,11 +87,27 @@ class _Side:
 SIDE = _Side()
 
 
-def grad_arena(D, n_layers, device):
-    """One zero-filled fp32 buffer for every parameter gradient of `n_layers` layers (one memset
-    instead of 6 per layer); returns per-layer (dWqkv, dbqkv, dW1, db1, dW2, db2) views."""
-    sizes = (3 * D * D, 3 * D, 4 * D * D, 4 * D, 4 * D * D, D)
-    shapes = ((3 * D, D), (3 * D,), (4 * D, D), (4 * D,), (D, 4 * D), (D,))
+class GradSink:
+    """Optional hook for data-parallel training (vitamd/ddp.py installs one): lets the transformer
+    stack's backward write each layer's parameter gradients straight into that layer's all-reduce
+    bucket and start the bucket's all-reduce the moment the layer is finished, instead of after the
+    whole stack (which is a single autograd node) has returned."""
+    sink = None
+
+
+def layer_sizes(D):
+    return (3 * D * D, 3 * D, 4 * D * D, 4 * D, 4 * D * D, D), ((3 * D, D), (3 * D,), (4 * D, D), (4 * D,), (D, 4 * D), (D,))
+
+
+def grad_arena(D, n_layers, device, params=None):
+    """Zero-filled fp32 storage for every parameter gradient of `n_layers` layers; returns per-layer
+    (dWqkv, dbqkv, dW1, db1, dW2, db2) views.  One buffer + one memset by default; the gradient
+    sink's per-layer buckets when one is installed for these parameters."""
+    sizes, shapes = layer_sizes(D)
+    if GradSink.sink is not None and params is not None:
+        got = GradSink.sink.arena_for(params, n_layers)
+        if got is not None:
+            return got
     per = sum(sizes)
     flat = torch.zeros(per * n_layers, dtype=F32, device=device)
     out = []
@@ -217,13 +233,18 @@ class TransformerStackFn(torch.autograd.Function):
         params = ctx.params
         n_saved = len(saved_all) // L
         cur = _f32c(g).view(B * N, D)
-        arena = grad_arena(D, L, cur.device)
+        arena = grad_arena(D, L, cur.device, params)
+        sink = GradSink.sink if (GradSink.sink is not None and GradSink.sink.owns(params)) else None
         dy2 = None
         for i in reversed(range(L)):
             wqkv, _, w1, _, w2, _ = params[6 * i: 6 * i + 6]
             nxt_db2 = arena[i - 1][5] if i > 0 else None      # layer i's first LN backward feeds layer i-1's fc2 bias grad
             cur, dy2 = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal, arena[i],
                                       dy2=dy2, have_db2=dy2 is not None, emit_bf16=i > 0, emit_colsum=nxt_db2)
+            if sink is not None and i + 1 < L:
+                sink.layer_ready(params, i + 1)   # layer i+1's bucket is complete once layer i's LN1 backward added its db2
+        if sink is not None:
+            sink.layer_ready(params, 0)
         join_side(cur.device)
         grads = [t for layer in arena for t in layer]
         return (cur.view(B, N, D).to(xdtype), None, None, *grads)
