@@ -51,6 +51,13 @@ int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, con
 int vitamd_gemm_tn_bf16(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
                         int splits, void* stream);
 
+/* Same GEMM with a caller-provided split-K workspace (>= splits * ceil(P/256) * ceil(Q/256) * 256 KiB,
+ * vitamd_gemm_tn_ws_bytes tells): partial tiles are written with plain stores and summed by a second
+ * pass (bitwise reproducible, ~4x the rate of the atomic form).  accumulate = 0 overwrites `out`. */
+int vitamd_gemm_tn_bf16_ws(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
+                           int splits, float* ws, long ws_bytes, int accumulate, void* stream);
+long vitamd_gemm_tn_ws_bytes(int R, int P, int Q, int splits);
+
 /* ---- LayerNorm (no affine, eps as given) on the fp32 residual stream -------------------------
  * forward: x = x_in (+ addend_bf16 -> also written to x_out); y = bf16(LN(x)); mean/rstd saved.
  * replaces transformer.py:43-44 `F.layer_norm(x, (n_embd,))` and the residual add of :43. */

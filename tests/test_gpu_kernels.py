@@ -113,10 +113,15 @@ def test_gemm_tn_exact_integers(hip, R, P, Q, splits):
     r = ints((R, Q), -3, 3, 12)
     init = ints((P, Q), -5, 5, 13)
     ref = init + l.t() @ r
-    out = init.to(dev())
-    ops.gemm_tn(l.to(dev(), BF16), r.to(dev(), BF16), out, splits=splits)
-    torch.cuda.synchronize()
-    assert torch.equal(out.cpu(), ref)
+    ld, rd = l.to(dev(), BF16), r.to(dev(), BF16)
+    for atomic in (True, False):                 # fp32 atomics / workspace + reduce pass
+        out = init.to(dev())
+        ops.gemm_tn(ld, rd, out, splits=splits, atomic=atomic)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref), atomic
+    out = torch.full((P, Q), 123.0, device=dev())
+    ops.gemm_tn(ld, rd, out, splits=splits, accumulate=False)   # overwrite mode needs no zeroing
+    assert torch.equal(out.cpu(), l.t() @ r)
 
 
 # ------------------------------------------------------------------------------------------ layernorm

@@ -14,7 +14,7 @@ from conftest import ROOT, load_golden
 def test_library_exports_every_declared_symbol():
     from vitamd import lib
     header = open(os.path.join(ROOT, "include", "vitamd.h")).read()
-    declared = set(re.findall(r"\bint\s+(vitamd_\w+)\s*\(", header))
+    declared = set(re.findall(r"\b(?:int|long)\s+(vitamd_\w+)\s*\(", header))
     assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
     if not os.path.exists(lib.LIB_PATH):
         lib.build()

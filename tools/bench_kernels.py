@@ -62,6 +62,9 @@ def main():
         rec(f"gemm_nt dfc1 plain  t{tile}", timeit(lambda: ops.gemm_nt(x3072, w2, ops.EPI_BIAS_BF16, tile=tile)), 2 * M * D * 4 * D)
         rec(f"gemm_nt dqkv plain  t{tile}", timeit(lambda: ops.gemm_nt(x2304, wqkv_t, ops.EPI_BIAS_BF16, tile=tile)), 2 * M * D * 3 * D)
     dW = torch.zeros(3 * D, D, device=dev)
+    rec("gemm_tn wgrad qkv (atomic)", timeit(lambda: ops.gemm_tn(x2304, x768, dW, atomic=True)), 2 * M * D * 3 * D)
+    dWa = torch.zeros(4 * D, D, device=dev)
+    rec("gemm_tn wgrad fc1 (atomic)", timeit(lambda: ops.gemm_tn(x3072, x768, dWa, atomic=True)), 2 * M * D * 4 * D)
     rec("gemm_tn wgrad qkv", timeit(lambda: ops.gemm_tn(x2304, x768, dW)), 2 * M * D * 3 * D)
     dW1 = torch.zeros(4 * D, D, device=dev)
     rec("gemm_tn wgrad fc1", timeit(lambda: ops.gemm_tn(x3072, x768, dW1)), 2 * M * D * 4 * D)

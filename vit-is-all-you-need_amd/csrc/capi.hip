@@ -20,6 +20,12 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
 
 extern "C" int vitamd_gemm_tn_bf16(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
                                    int splits, void* stream) {
-  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits};
+  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits, nullptr, 0, 1};
+  return vitamd_gemm_tn_impl(a, (hipStream_t)stream);
+}
+
+extern "C" int vitamd_gemm_tn_bf16_ws(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
+                                      int splits, float* ws, long ws_bytes, int accumulate, void* stream) {
+  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits, ws, (size_t)(ws_bytes < 0 ? 0 : ws_bytes), accumulate};
   return vitamd_gemm_tn_impl(a, (hipStream_t)stream);
 }

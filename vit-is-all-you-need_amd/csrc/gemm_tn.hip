@@ -33,6 +33,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+template <bool WS>
 __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -49,34 +50,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(const GemmTnArgs a, in
   const int s_lo = (int)((long)nsteps * split / splits), s_hi = (int)((long)nsteps * (split + 1) / splits);
   if (s_lo >= s_hi) return;
 
-  const auto rsrcL = __builtin_amdgcn_make_buffer_rsrc((void*)a.L, 0, (int)((size_t)a.R * a.ldl * 2), 0x00020000);
-  const auto rsrcR = __builtin_amdgcn_make_buffer_rsrc((void*)a.Rm, 0, (int)((size_t)a.R * a.ldr * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcL = make_rsrc(a.L, (size_t)a.R * a.ldl * 2);
+  const __amdgpu_buffer_rsrc_t rsrcR = make_rsrc(a.Rm, (size_t)a.R * a.ldr * 2);
 
-  // this wave's pieces: waves 0-3 stage L rows, waves 4-7 stage R rows (16 rows each per stage)
+  // this wave's pieces: waves 0-3 stage L rows, waves 4-7 stage R rows (16 rows each per stage).
+  // Rows past R and columns past the matrix edge must read as ZERO (they enter the reduction): rows
+  // fall out of the descriptor's range by themselves, edge columns get an offset of 2 GiB (buffers
+  // are < 2 GiB, checked on the host; the per-step byte offset rides in the scalar offset).
   const bool isL = wave < NW / 2;
   const int ld = isL ? a.ldl : a.ldr;
   const int c0 = isL ? p0 : q0;
   const int ncols = isL ? a.P : a.Q;
+  const __amdgpu_buffer_rsrc_t rsrc = isL ? rsrcL : rsrcR;
   unsigned voff[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int row = ((wave & 3) * PPW + i) * 2 + (lane >> 5);
     const int logical = (lane & 31) ^ ((row & 3) << 2);
-    int col = c0 + logical * 8;
-    // columns past the matrix edge: point far out of range so the DMA writes zeros
-    voff[i] = (col < ncols) ? (unsigned)(((size_t)(s_lo * BR + row) * ld + col) * 2) : 0xfffffff0u;
+    const int col = c0 + logical * 8;
+    voff[i] = (col < ncols) ? (unsigned)(((size_t)row * ld + col) * 2) : 0x80000000u;
   }
   const unsigned step_bytes = (unsigned)BR * ld * 2;
-
-  auto stage = [&](int buf) {
-    char* base = smem + buf * BUF_BYTES + (isL ? 0 : TILE_BYTES) + (wave & 3) * PPW * 1024;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      if (isL) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcL, (LDS_AS void*)(base + i * 1024), 16, voff[i], 0, 0, 0);
-      else     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (LDS_AS void*)(base + i * 1024), 16, voff[i], 0, 0, 0);
-      if (voff[i] < 0xf0000000u) voff[i] += step_bytes;
-    }
-  };
+  char* const stage_base = smem + (isL ? 0 : TILE_BYTES) + (wave & 3) * PPW * 1024;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -102,63 +97,138 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(const GemmTnArgs a, in
     offB[j] = TILE_BYTES + rowpart + ((chunk ^ (qq << 2)) << 4);
   }
 
-  stage(0);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) buf_glds16(rsrc, stage_base + i * 1024, voff[i], s_lo * step_bytes);
   for (int s = s_lo; s < s_hi; ++s) {
     const int cur = (s - s_lo) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s + 1 < s_hi) stage(cur ^ 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     const char* buf = smem + cur * BUF_BYTES;
+    char* nbase = stage_base + (cur ^ 1) * BUF_BYTES;
+    const bool more = s + 1 < s_hi;
+    const int soff = (s + 1) * step_bytes;
+    // four 16-deep groups of 8 MFMAs; each first issues two DMA pieces of the next stage and the
+    // transposed reads of the NEXT group's fragments (register double buffer), then its MFMAs
+    bf16x8 af[2][MT], bfr[2][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[0][j] = tr_frag(buf + offB[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[0][i] = tr_frag(buf + offA[i]);
 #pragma unroll
     for (int ks = 0; ks < BR / 16; ++ks) {
-      bf16x8 af[MT], bfr[NT];
+      if (more) {
+        buf_glds16(rsrc, nbase + (2 * ks) * 1024, voff[2 * ks], soff);
+        buf_glds16(rsrc, nbase + (2 * ks + 1) * 1024, voff[2 * ks + 1], soff);
+      }
+      if (ks + 1 < BR / 16) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = tr_frag(buf + offB[j] + ks * 16 * 512);
+        for (int j = 0; j < NT; ++j) bfr[(ks + 1) & 1][j] = tr_frag(buf + offB[j] + (ks + 1) * 16 * 512);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = tr_frag(buf + offA[i] + ks * 16 * 512);
+        for (int i = 0; i < MT; ++i) af[(ks + 1) & 1][i] = tr_frag(buf + offA[i] + (ks + 1) * 16 * 512);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
   // D[i = p][j = q]: col q = lane&31, row p = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if constexpr (WS) {
+    // partial tile -> workspace with plain stores (one accumulator register = two 128-B row
+    // segments); the reduce pass sums the splits.  ~4-5x the rate of fp32 atomics.
+    float* wt = a.ws + ((size_t)split * ntile + tile) * (BP * BQ);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int q = q0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
+    for (int j = 0; j < NT; ++j) {
+      const int ql = wq * (BQ / WQ) + j * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int pbase = p0 + wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
+      for (int i = 0; i < MT; ++i) {
+        const int pl = wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = pbase + (r & 3) + 8 * (r >> 2);
-        if (p < a.P && q < a.Q) atomicAdd(a.out + (size_t)p * a.ldo + q, acc[i][j][r]);
+        for (int r = 0; r < 16; ++r) wt[(pl + (r & 3) + 8 * (r >> 2)) * BQ + ql] = acc[i][j][r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int q = q0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int pbase = p0 + wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = pbase + (r & 3) + 8 * (r >> 2);
+          if (p < a.P && q < a.Q) atomicAdd(a.out + (size_t)p * a.ldo + q, acc[i][j][r]);
+        }
       }
     }
   }
 }
 
+// out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; one float4 per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int Q, int ldo,
+                                                            int tiles_q, int ntile, int splits, int accumulate) {
+  const int tile = blockIdx.y;
+  const int p0 = (tile / tiles_q) * BP, q0 = (tile % tiles_q) * BQ;
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // float4 index inside the tile: 64 per row
+  const int pl = idx >> 6, ql = (idx & 63) * 4;
+  const int p = p0 + pl, q = q0 + ql;
+  if (p >= P || q >= Q) return;
+  const float* src = ws + (size_t)tile * (BP * BQ) + pl * BQ + ql;
+  f32x4 sum = *(const f32x4*)src;
+  for (int s2 = 1; s2 < splits; ++s2) sum += *(const f32x4*)(src + (size_t)s2 * ntile * (BP * BQ));
+  float* dst = out + (size_t)p * ldo + q;
+  if (q + 3 < Q && (ldo & 3) == 0) {
+    if (accumulate) sum += *(const f32x4*)dst;
+    *(f32x4*)dst = sum;
+  } else {
+    for (int c = 0; c < 4 && q + c < Q; ++c) dst[c] = accumulate ? dst[c] + sum[c] : sum[c];
+  }
+}
+
 }  // namespace
+
+static int auto_splits(int R, int P, int Q, int requested) {
+  const int ntile = ((P + BP - 1) / BP) * ((Q + BQ - 1) / BQ);
+  const int nsteps = (R + BR - 1) / BR;
+  int splits = requested;
+  if (splits <= 0) splits = ntile >= 256 ? 1 : 256 / ntile;
+  if (splits > nsteps) splits = nsteps;
+  return splits;
+}
+
+extern "C" long vitamd_gemm_tn_ws_bytes(int R, int P, int Q, int splits) {
+  if (R <= 0 || P <= 0 || Q <= 0) return 0;
+  const long ntile = (long)((P + BP - 1) / BP) * ((Q + BQ - 1) / BQ);
+  return (long)auto_splits(R, P, Q, splits) * ntile * BP * BQ * (long)sizeof(float);
+}
 
 int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   if (a.R <= 0 || a.P <= 0 || a.Q <= 0 || a.ldl % 8 || a.ldr % 8 || a.ldl < a.P || a.ldr < a.Q || a.ldo < a.Q) return VITAMD_ERR_SHAPE;
-  if ((size_t)a.R * a.ldl * 2 >= 0xf0000000ull || (size_t)a.R * a.ldr * 2 >= 0xf0000000ull) return VITAMD_ERR_SHAPE;
+  if ((size_t)(a.R + BR) * a.ldl * 2 >= 0x80000000ull || (size_t)(a.R + BR) * a.ldr * 2 >= 0x80000000ull) return VITAMD_ERR_SHAPE;
   if (!a.L || !a.Rm || !a.out) return VITAMD_ERR_ARG;
   const int tiles_p = (a.P + BP - 1) / BP, tiles_q = (a.Q + BQ - 1) / BQ;
   const int ntile = tiles_p * tiles_q;
   const int nsteps = (a.R + BR - 1) / BR;
-  int splits = a.splits;
-  if (splits <= 0) splits = ntile >= 256 ? 1 : 256 / ntile;
-  if (splits > nsteps) splits = nsteps;
+  const int splits = auto_splits(a.R, a.P, a.Q, a.splits);
   static bool attr_done = false;
   constexpr int lds = 2 * BUF_BYTES;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return VITAMD_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
+  const bool use_ws = a.ws != nullptr && a.ws_bytes >= (size_t)splits * ntile * BP * BQ * sizeof(float);
+  if (use_ws) {
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q,
+                       ntile, splits, a.accumulate);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
+  }
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

@@ -32,6 +32,9 @@ struct GemmTnArgs {
   float* out;      // [P, Q] fp32, ACCUMULATED into (atomics)
   int R, P, Q, ldl, ldr, ldo;
   int splits;      // 0 = auto
+  float* ws;       // optional split-K workspace: [splits][tiles][256][256] fp32 partial tiles (plain stores) + reduce pass
+  size_t ws_bytes;
+  int accumulate;  // with a workspace: 1 = out += sum, 0 = out = sum (no pre-zeroing needed)
 };
 
 extern int g_vitamd_debug;

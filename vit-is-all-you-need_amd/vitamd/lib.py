@@ -22,6 +22,8 @@ SIGNATURES = {
     "vitamd_abi_version": [],
     "vitamd_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vitamd_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vitamd_gemm_tn_bf16_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P],
+    "vitamd_gemm_tn_ws_bytes": [_I, _I, _I, _I],
     "vitamd_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "vitamd_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -64,7 +66,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_long if name.endswith("_bytes") else ctypes.c_int
     if lib.vitamd_abi_version() != ABI_VERSION:
         raise VitamdError("libvitamd.so ABI version mismatch; rebuild")
     _lib = lib

@@ -61,14 +61,35 @@ def gemm_nt(a, b, epi, *, bias=None, aux=None, out=None, out2=None, colsum=None,
     return (out, out2) if epi == EPI_GELU else out
 
 
-def gemm_tn(l, r, out, splits=0):
-    """out[P,Q] (fp32) += l[R,P]^T @ r[R,Q]."""
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    """split-K scratch, one per (device, stream): kernels on different streams never share it"""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WORKSPACES[key] = torch.empty((nbytes + 3) // 4, dtype=F32, device=device)
+    return ws
+
+
+def gemm_tn(l, r, out, splits=0, accumulate=True, atomic=False):
+    """out[P,Q] (fp32) (+)= l[R,P]^T @ r[R,Q].  Split-K partials go through a workspace + reduce
+    pass (reproducible) unless atomic=True (fp32 atomics straight into `out`, accumulate only)."""
     _need(l, BF16, "l", 2); _need(r, BF16, "r", 2); _need(out, F32, "out", 2)
     R, P = l.shape
     R2, Q = r.shape
     if R != R2 or tuple(out.shape) != (P, Q):
         raise _lib.VitamdError("gemm_tn: shape mismatch")
-    code = _L().vitamd_gemm_tn_bf16(_p(l), _p(r), _p(out), R, P, Q, P, Q, Q, splits, _stream())
+    if atomic:
+        if not accumulate:
+            raise _lib.VitamdError("gemm_tn: the atomic form can only accumulate")
+        code = _L().vitamd_gemm_tn_bf16(_p(l), _p(r), _p(out), R, P, Q, P, Q, Q, splits, _stream())
+    else:
+        nbytes = _L().vitamd_gemm_tn_ws_bytes(R, P, Q, splits)
+        ws = _workspace(l.device, nbytes)
+        code = _L().vitamd_gemm_tn_bf16_ws(_p(l), _p(r), _p(out), R, P, Q, P, Q, Q, splits, _p(ws), ws.numel() * 4, int(accumulate),
+                                           _stream())
     _lib.check(code, f"gemm_tn[R={R},P={P},Q={Q}]")
     return out
 
