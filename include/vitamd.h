@@ -93,6 +93,12 @@ int vitamd_colsum_bf16(const void* x_bf16, float* out, int M, int N, int ld, voi
 int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16, float* dbias, int B, int seq,
                      int extra, int D, void* stream);
 
+/* ---- optimiser -------------------------------------------------------------------------------
+ * One fused AdamW update (decoupled weight decay, bias correction for 1-based `step`) of n fp32
+ * parameters in place; m, v are the optimiser state.  replaces train_vit.py:82,105 (torch.optim.AdamW). */
+int vitamd_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,7 @@ SIGNATURES = {
     "vitamd_im2col_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "vitamd_colsum_bf16": [_P, _P, _I, _I, _I, _P],
     "vitamd_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vitamd_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
 }
 
 ERRORS = {1: "unsupported shape", 2: "bad argument", 3: "HIP launch failure"}
