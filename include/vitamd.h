@@ -93,6 +93,11 @@ int vitamd_colsum_bf16(const void* x_bf16, float* out, int M, int N, int ld, voi
 int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16, float* dbias, int B, int seq,
                      int extra, int D, void* stream);
 
+/* ---- VQ quantiser (TiTok / ViT-VQGAN) --------------------------------------
+ * idx[m] = argmin_k ||x[m,:] - codebook[k,:]||^2, first minimum, fp32; d <= 64; idx is int64.
+ * replaces train_titok.py:53 / train_vit_vqgan.py:52 `torch.cdist(x, embedding).argmin(dim=-1)`. */
+int vitamd_vq_nearest(const float* x, const float* codebook, long long* idx, int M, int K, int d, void* stream);
+
 /* ---- optimiser -------------------------------------------------------------------------------
  * One fused AdamW update (decoupled weight decay, bias correction for 1-based `step`) of n fp32
  * parameters in place; m, v are the optimiser state.  replaces train_vit.py:82,105 (torch.optim.AdamW). */

@@ -59,6 +59,9 @@ def import_reference():
     _placeholder("vector_quantize_pytorch", FSQ=None)
     import train_vit as ref_train_vit
     import utils as ref_utils
+    global REF_TITOK, REF_VQGAN
+    import train_titok as REF_TITOK
+    import train_vit_vqgan as REF_VQGAN
 
     return ref_transformer, ref_train_vit, ref_utils
 
@@ -220,6 +223,59 @@ def gen_train_steps_fixture(TV, RU):
                                 "final_head_bias": model.head.bias.detach().clone()})
 
 
+def gen_tokenizer_fixture(name, model, sd, images, extra_cfg):
+    """TiTok / ViT-VQGAN: reconstruction, indices, quantiser loss, encoder latents and the gradients of
+    mse(recon, images) + quantize_loss (the perceptual term needs network weights: out of scope)."""
+    model.load_state_dict(sd, strict=True)
+
+    def run(autocast_bf16):
+        model.zero_grad(set_to_none=True)
+        if autocast_bf16:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                recon, idx, ql = model(images)
+        else:
+            recon, idx, ql = model(images)
+        loss = torch.nn.functional.mse_loss(recon.float(), images) + ql.float()
+        loss.backward()
+        return recon.detach().float(), idx.detach(), float(ql), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    enc = model.enc if hasattr(model, "enc") else model.encoder
+    latents = enc(images).detach()
+    recon, idx, ql, loss, grads = run(False)
+    r16, i16, q16, l16, g16 = run(True)
+    with torch.no_grad():
+        recon_fixed = model.decode_indices(idx).float()
+    save(name, {
+        "cfg": extra_cfg, "n_params": sum(p.numel() for p in model.parameters()),
+        "state_keys": sorted(model.state_dict().keys()),
+        "state_shapes": {k: list(v.shape) for k, v in model.state_dict().items()},
+        "latents": latents, "indices": idx, "quantize_loss": ql, "loss": loss,
+        "recon": summarize(recon), "recon_from_indices": summarize(recon_fixed),
+        "grads": {k: summarize(v) for k, v in grads.items()},
+        "ref_bf16_floor": {"recon": rel_l2(r16, recon), "index_agreement": float((i16 == idx).float().mean()),
+                           "loss_abs": abs(l16 - loss), "grads": {k: rel_l2(g16[k], grads[k]) for k in grads}},
+    })
+
+
+def gen_tokenizer_fixtures():
+    # BASELINE configs[3]: TiTok-S 256x256, 32 latent tokens, codebook 2048 x 12
+    seed, B = 31, 2
+    cfg = REF_TITOK.TiTokConfig(256, 16, 32, 2048, 12, "S")
+    sd = W.tokenizer_state(seed, "enc.", "quant.", "dec.", 256, 32, 32, 256, 16, 6, 512, 2048, 12)
+    images = W.uniform(seed, "images", (B, 3, 256, 256), 0.5) + 0.5
+    gen_tokenizer_fixture("titok_s256.pt", REF_TITOK.TiTok(cfg), sd, images,
+                          {"seed": seed, "batch": B, "image_size": 256, "patch": 16, "latent_tokens": 32, "codebook_size": 2048,
+                           "latent_dim": 12, "preset": "S", "n_layers": 6, "n_embd": 512})
+    # BASELINE configs[4] model: ViT-VQGAN-B 256x256 (0 extra tokens, one latent per patch)
+    seed, B = 32, 1
+    cfg = REF_VQGAN.ViTVQGANConfig(256, 16, 2048, 12, "B")
+    sd = W.tokenizer_state(seed, "encoder.", "quant.", "decoder.", 256, 256, 0, 0, 16, 12, 768, 2048, 12)
+    images = W.uniform(seed, "images", (B, 3, 256, 256), 0.5) + 0.5
+    gen_tokenizer_fixture("vitvqgan_b256.pt", REF_VQGAN.ViTVQGAN(cfg), sd, images,
+                          {"seed": seed, "batch": B, "image_size": 256, "patch": 16, "latent_tokens": 256, "codebook_size": 2048,
+                           "latent_dim": 12, "preset": "B", "n_layers": 12, "n_embd": 768})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -229,6 +285,7 @@ def main():
     gen_classifier_fixture(TV, "vit_b224.pt", 224, "B", 1000, 2, seed=14)                 # BASELINE config 2 shape
     gen_lr_fixture(RU)
     gen_train_steps_fixture(TV, RU)
+    gen_tokenizer_fixtures()
 
 
 if __name__ == "__main__":

@@ -211,6 +211,51 @@ def cross_entropy(logits, labels):
 
 
 # --------------------------------------------------------------------------------------
+# 1-D / 2-D VQ tokenizers on top of the ViT
+# --------------------------------------------------------------------------------------
+def vq_quantize(x, codebook):
+    """Reference train_titok.py:50-59 / train_vit_vqgan.py:49-58: L2-normalise the latents, nearest
+    NORMALISED code by Euclidean distance, look up the RAW code, codebook + 0.25 commitment MSE,
+    straight-through output."""
+    xn = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    en = codebook / codebook.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    d2 = (xn.detach().unsqueeze(-2) - en.detach()).pow(2).sum(-1)        # [..., K]
+    idx = d2.argmin(dim=-1)
+    q = codebook[idx]
+    qloss = (q - xn.detach()).pow(2).mean() + 0.25 * (q.detach() - xn).pow(2).mean()
+    return xn + (q - xn).detach(), idx, qloss
+
+
+def pixel_shuffle(tokens, grid, p):
+    """'b (h w) c -> b c h w' then 'b (p1 p2 c) h w -> b c (h p1) (w p2)' (train_titok.py:73-75)."""
+    B, _, F = tokens.shape
+    c = F // (p * p)
+    return tokens.reshape(B, grid, grid, p, p, c).permute(0, 5, 1, 3, 2, 4).reshape(B, c, grid * p, grid * p)
+
+
+def tokenizer_forward(images, sd, enc, quant, dec, enc_cfg: OracleViTConfig, dec_cfg: OracleViTConfig, keep_enc, keep_dec,
+                      grid, patch, lowp=False, indices=None):
+    """TiTok (train_titok.py:40-43,69-77,89-93) and ViT-VQGAN (train_vit_vqgan.py:40-43,67-74,86-90):
+    ViT encoder -> Linear -> VQ -> Linear -> 'b h c -> b c h 1' -> ViT decoder (1x1 patches) ->
+    1x1 conv -> pixel shuffle.  keep_* = how many leading tokens each ViT output keeps (None = all)."""
+    tok = vit(images, sd, enc + "vit.", enc_cfg, lowp)
+    if keep_enc is not None:
+        tok = tok[:, :keep_enc]
+    latents = linear(tok, sd[enc + "proj.weight"], sd[enc + "proj.bias"], lowp)
+    quantized, idx, qloss = vq_quantize(latents, sd[quant + "codebook.weight"])
+    if indices is not None:                                   # decode a prescribed code sequence instead
+        quantized = sd[quant + "codebook.weight"][indices]
+    z = linear(quantized, sd[dec + "quant_proj.weight"], sd[dec + "quant_proj.bias"], lowp)
+    z = z.transpose(1, 2).unsqueeze(-1)                       # [b, c, h, 1]
+    out = vit(z, sd, dec + "vit.", dec_cfg, lowp)
+    if keep_dec is not None:
+        out = out[:, :keep_dec]
+    w = sd[dec + "embd_proj.weight"]
+    y = linear(out, w.reshape(w.shape[0], -1), sd[dec + "embd_proj.bias"], lowp)
+    return pixel_shuffle(y, grid, patch), idx, qloss, latents
+
+
+# --------------------------------------------------------------------------------------
 # LR schedule (reference utils.py:5-9), closed form
 # --------------------------------------------------------------------------------------
 def lr_at(step: int, base_lr: float, warmup_steps: int, train_steps: int, min_lr: float) -> float:

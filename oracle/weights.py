@@ -77,3 +77,24 @@ def classifier_state(seed, in_channels, patch, n_patches, extra, n_layers, n_emb
     sd["head.weight"] = uniform(seed, "head.w", (num_classes, n_embd), b)
     sd["head.bias"] = uniform(seed, "head.b", (num_classes,), b)
     return sd
+
+
+def linear_state(seed, prefix, out_f, in_f) -> dict:
+    b = 1.0 / np.sqrt(in_f)
+    return {prefix + "weight": uniform(seed, prefix + "w", (out_f, in_f), b), prefix + "bias": uniform(seed, prefix + "b", (out_f,), b)}
+
+
+def tokenizer_state(seed, enc, quant, dec, image_patches, latent_tokens, enc_extra, dec_extra, patch, n_layers, n_embd,
+                    codebook_size, latent_dim) -> dict:
+    """Parameters of reference train_titok.TiTok (enc='enc.', quant='quant.', dec='dec.') or
+    train_vit_vqgan.ViTVQGAN (enc='encoder.', dec='decoder.'): two ViTs, three projections, codebook."""
+    D = n_embd
+    sd = vit_state(seed, enc + "vit.", 3, patch, image_patches, enc_extra, n_layers, D)
+    sd.update(linear_state(seed, enc + "proj.", latent_dim, D))
+    sd[quant + "codebook.weight"] = uniform(seed, quant + "codebook", (codebook_size, latent_dim), 1.0 / codebook_size)  # train_titok.py:49
+    sd.update(vit_state(seed, dec + "vit.", D, 1, latent_tokens, dec_extra, n_layers, D))
+    sd.update(linear_state(seed, dec + "quant_proj.", D, latent_dim))
+    ep = linear_state(seed, dec + "embd_proj.", 3 * patch * patch, D)
+    ep[dec + "embd_proj.weight"] = ep[dec + "embd_proj.weight"].reshape(3 * patch * patch, D, 1, 1)  # Conv2d(k=1) weight
+    sd.update(ep)
+    return sd

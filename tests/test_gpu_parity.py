@@ -210,3 +210,56 @@ def test_training_steps_match_reference_loop(hip):
     for a, b in zip(losses, ref):
         assert abs(a - b) < 3e-2 * max(1.0, abs(b)), (losses, ref)
     assert O.rel_l2(m.head.bias.detach().cpu(), g["final_head_bias"]) < 5e-2
+
+
+# ------------------------------------------------------------------ tokenizers (BASELINE configs[3], [4])
+def _tokenizer_model(name):
+    import weights as W2
+    from test_oracle import TOKENIZERS
+    g = load_golden(name)
+    c, t = g["cfg"], TOKENIZERS[name]
+    n_img_patches = (c["image_size"] // c["patch"]) ** 2
+    sd = W2.tokenizer_state(c["seed"], t["enc"], t["quant"], t["dec"], n_img_patches, c["latent_tokens"], t["enc_extra"], t["dec_extra"],
+                            c["patch"], c["n_layers"], c["n_embd"], c["codebook_size"], c["latent_dim"])
+    if name.startswith("titok"):
+        import train_titok as TT
+        m = TT.TiTok(TT.TiTokConfig(c["image_size"], c["patch"], c["latent_tokens"], c["codebook_size"], c["latent_dim"], c["preset"]))
+        enc = m.enc
+    else:
+        import train_vit_vqgan as TQ
+        m = TQ.ViTVQGAN(TQ.ViTVQGANConfig(c["image_size"], c["patch"], c["codebook_size"], c["latent_dim"], c["preset"]))
+        enc = m.encoder
+    assert sorted(m.state_dict().keys()) == g["state_keys"]
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == g["state_shapes"]
+    m.load_state_dict(sd, strict=True)
+    images = W2.uniform(c["seed"], "images", (c["batch"], 3, c["image_size"], c["image_size"]), 0.5) + 0.5
+    return g, m.cuda(), enc, images.cuda()
+
+
+@pytest.mark.parametrize("name", ["titok_s256.pt", "vitvqgan_b256.pt"])
+def test_tokenizer_vs_reference_golden(hip, name):
+    g, m, enc, images = _tokenizer_model(name)
+    floor = g["ref_bf16_floor"]
+    with torch.no_grad():
+        latents = enc(images)
+        recon_fixed = m.decode_indices(g["indices"].cuda())     # decoder alone, on the reference's own code sequence
+    assert O.rel_l2(latents.cpu(), g["latents"]) < 2e-2          # latents are 12-dim projections of a 6/12-layer bf16 stack
+    assert _err(recon_fixed, g["recon_from_indices"]) < 2 * floor["recon"] + 3e-3
+    recon, idx, qloss = m(images)
+    agree = float((idx.cpu() == g["indices"]).float().mean())
+    assert agree >= min(floor["index_agreement"], 1.0) - 0.03, agree   # nearest-code decisions may flip on near-ties
+    assert abs(float(qloss) - g["quantize_loss"]) < 2e-3
+    loss = torch.nn.functional.mse_loss(recon, images) + qloss
+    assert abs(float(loss) - g["loss"]) < 5e-3
+    loss.backward()
+    torch.cuda.synchronize()
+    bad = []
+    for k, p in m.named_parameters():
+        ref = g["grads"][k]
+        if p.grad is None or ref["norm"] == 0.0 or p.numel() == 0:
+            continue
+        assert torch.isfinite(p.grad).all(), k
+        e = _err(p.grad, ref)
+        if e > 3 * floor["grads"][k] + 2e-2:
+            bad.append((k, round(e, 4), round(floor["grads"][k], 4)))
+    assert not bad, bad[:8]

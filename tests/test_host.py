@@ -98,3 +98,17 @@ def test_shard_batch():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_tokenizer_surfaces_match_reference_checkpoints():
+    import train_titok as TT
+    import train_vit_vqgan as TQ
+    g = load_golden("titok_s256.pt")
+    m = TT.TiTok(TT.TiTokConfig(256, 16, 32, 2048, 12, "S"))
+    assert sorted(m.state_dict().keys()) == g["state_keys"] and sum(p.numel() for p in m.parameters()) == g["n_params"] == 36_034_828
+    assert m.config.dec_vit_config.n_patches == 32 and m.dec.vit.extra_emb.weight.shape == (256, 512)
+    g = load_golden("vitvqgan_b256.pt")
+    v = TQ.ViTVQGAN(TQ.ViTVQGANConfig(256, 16, 2048, 12, "B"))
+    assert sorted(v.state_dict().keys()) == g["state_keys"] and sum(p.numel() for p in v.parameters()) == g["n_params"] == 158_069_772
+    assert {k: list(t.shape) for k, t in v.state_dict().items()} == g["state_shapes"]
+    assert float(m.quant.codebook.weight.abs().max()) <= 1.0 / 2048 + 1e-9          # reference init (train_titok.py:49)

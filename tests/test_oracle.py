@@ -101,3 +101,48 @@ def test_lr_schedule_matches_reference_trace():
     for s, lr in enumerate(g["lrs"].tolist()):
         mine = O.lr_at(s, g["base_lr"], g["warmup_steps"], g["train_steps"], g["min_lr"])
         assert abs(mine - lr) < 1e-12, (s, mine, lr)
+
+
+# ------------------------------------------------------------------ tokenizers
+TOKENIZERS = {
+    "titok_s256.pt": dict(enc="enc.", quant="quant.", dec="dec.", enc_extra=32, dec_extra=256, keep_enc=32, keep_dec=256),
+    "vitvqgan_b256.pt": dict(enc="encoder.", quant="quant.", dec="decoder.", enc_extra=0, dec_extra=0, keep_enc=None, keep_dec=None),
+}
+
+
+def tokenizer_setup(name):
+    g = load_golden(name)
+    c, t = g["cfg"], TOKENIZERS[name]
+    heads = O.PRESETS[c["preset"]][1]
+    n_img_patches = (c["image_size"] // c["patch"]) ** 2
+    sd = W.tokenizer_state(c["seed"], t["enc"], t["quant"], t["dec"], n_img_patches, c["latent_tokens"], t["enc_extra"], t["dec_extra"],
+                           c["patch"], c["n_layers"], c["n_embd"], c["codebook_size"], c["latent_dim"])
+    enc_cfg = O.OracleViTConfig(c["image_size"], 3, c["patch"], c["n_layers"], heads, c["n_embd"], t["enc_extra"])
+    dec_cfg = O.OracleViTConfig(c["latent_tokens"], c["n_embd"], 1, c["n_layers"], heads, c["n_embd"], t["dec_extra"], n_patches=c["latent_tokens"])
+    images = W.uniform(c["seed"], "images", (c["batch"], 3, c["image_size"], c["image_size"]), 0.5) + 0.5
+    return g, c, t, sd, enc_cfg, dec_cfg, images
+
+
+def test_tokenizers_match_reference():
+    for name in TOKENIZERS:
+        g, c, t, sd, enc_cfg, dec_cfg, images = tokenizer_setup(name)
+        assert sorted(sd.keys()) == g["state_keys"]
+        assert {k: list(v.shape) for k, v in sd.items()} == g["state_shapes"]
+        assert sum(v.numel() for v in sd.values()) == g["n_params"]
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        grid = c["image_size"] // c["patch"]
+        recon, idx, qloss, latents = O.tokenizer_forward(images, leaves, t["enc"], t["quant"], t["dec"], enc_cfg, dec_cfg,
+                                                         t["keep_enc"], t["keep_dec"], grid, c["patch"])
+        assert O.rel_l2(latents, g["latents"]) < 1e-5
+        assert torch.equal(idx, g["indices"])
+        assert abs(float(qloss) - g["quantize_loss"]) < 1e-6
+        assert _err(recon, g["recon"]) < 1e-5
+        loss = ((recon - images) ** 2).mean() + qloss
+        assert abs(float(loss) - g["loss"]) < 1e-6
+        grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+        for (k, _), gr in zip(leaves.items(), grads):
+            ref = g["grads"][k]
+            if ref["norm"] == 0.0:
+                assert gr is None or gr.numel() == 0 or float(gr.abs().max()) == 0.0, k
+            else:
+                assert _err(gr, ref) < 2e-4, k

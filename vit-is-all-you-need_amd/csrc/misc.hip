@@ -143,7 +143,46 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   }
 }
 
+// idx[m] = argmin_k || x[m,:] - e[k,:] ||^2 (first minimum), fp32; the nearest-code search of the
+// VQ quantisers (reference train_titok.py:53 `torch.cdist(x, embedding).argmin(dim=-1)`).
+// One thread per row, the codebook streamed through LDS in chunks of 256 codes.
+template <int DMAX>
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ x, const float* __restrict__ e,
+                                                         long long* __restrict__ idx, int M, int K, int d) {
+  __shared__ float ce[256 * DMAX];
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  float xr[DMAX];
+#pragma unroll
+  for (int c = 0; c < DMAX; ++c) xr[c] = (m < M && c < d) ? x[(size_t)m * d + c] : 0.f;
+  float best = 3.0e38f;
+  int besti = 0;
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    const int nk = min(256, K - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk * d; i += 256) ce[(i / d) * DMAX + (i % d)] = e[(size_t)k0 * d + i];
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c) {
+        if (c < d) { const float t = xr[c] - ce[k * DMAX + c]; s += t * t; }
+      }
+      if (s < best) { best = s; besti = k0 + k; }
+    }
+  }
+  if (m < M) idx[m] = besti;
+}
+
 }  // namespace
+
+extern "C" int vitamd_vq_nearest(const float* x, const float* codebook, long long* idx, int M, int K, int d, void* stream) {
+  if (M <= 0 || K <= 0 || d <= 0 || d > 64) return VITAMD_ERR_SHAPE;
+  if (!x || !codebook || !idx) return VITAMD_ERR_ARG;
+  const int grid = (M + 255) / 256;
+  if (d <= 16) hipLaunchKernelGGL(vq_nearest_kernel<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, codebook, idx, M, K, d);
+  else hipLaunchKernelGGL(vq_nearest_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, codebook, idx, M, K, d);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
 
 extern "C" int vitamd_cast_f32_bf16(const float* in, void* out_bf16, long n, void* stream) {
   if (n <= 0) return n == 0 ? VITAMD_OK : VITAMD_ERR_SHAPE;

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from transformer import Transformer, transformer_configs
 from utils import get_lr_scheduler
-from vitamd.functions import LinearFn, PatchEmbedFn
+from vitamd.functions import PatchEmbedFn, linear
 
 
 @dataclass
@@ -58,7 +58,7 @@ class ViTClassifier(nn.Module):
         self.head = nn.Linear(vit_config.trans_config.n_embd, num_classes)
 
     def forward(self, x):
-        return LinearFn.apply(self.vit(x)[:, 0].contiguous(), self.head.weight, self.head.bias)
+        return linear(self.vit(x)[:, 0], self.head.weight, self.head.bias)
 
 
 def train_step(model, images, labels, optim, lr_sched=None, loss_fn=None):

@@ -152,19 +152,19 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
         dy2 = ops.cast_bf16(g2)
     # ---- MLP
     def wgrad_fc2():
-        ops.gemm_tn(dy2, h, dW2)
+        ops.gemm_tn(dy2, h, dW2, accumulate=False)
         if not have_db2:
             ops.colsum(dy2, db2)
     on_side(wgrad_fc2, dy2, h, dW2, db2)
     dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)            # dgrad fc2 . gelu'
-    on_side(lambda: ops.gemm_tn(dpre, bln, dW1), dpre, bln, dW1)
+    on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False), dpre, bln, dW1)
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True)
     # ---- attention
     dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal)
 
     def wgrad_qkv():
-        ops.gemm_tn(dqkv, a, dWqkv)
+        ops.gemm_tn(dqkv, a, dWqkv, accumulate=False)
         ops.colsum(dqkv, dbqkv)
     on_side(wgrad_qkv, dqkv, a, dWqkv, dbqkv)
     da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
@@ -275,8 +275,8 @@ class AttentionFn(torch.autograd.Function):
         _, wt = WEIGHTS.get(ctx.wqkv, True)
         d_o = ops.cast_bf16(_f32c(g).view(B * N, D))
         dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal)
-        dW = torch.zeros((3 * D, D), dtype=F32, device=g.device)
-        ops.gemm_tn(dqkv, xb, dW)
+        dW = torch.empty((3 * D, D), dtype=F32, device=g.device)
+        ops.gemm_tn(dqkv, xb, dW, accumulate=False)
         db = ops.colsum(dqkv)
         dx = ops.gemm_nt(dqkv, wt, ops.EPI_BIAS_BF16)
         return dx.view(B, N, D).to(xdtype), dW, db, None, None
@@ -292,11 +292,11 @@ class PatchEmbedFn(torch.autograd.Function):
         D = conv_w.shape[0]
         extra = extra_w.shape[0]
         seq = n_patches + extra
-        need_grad = any(ctx.needs_input_grad[1:])
+        need_grad = any(ctx.needs_input_grad)
         patches = ops.im2col(_f32c(images), patch)  # [B*np, C*p*p] bf16
         if patches.shape[0] != B * n_patches:
             raise ops._lib.VitamdError(f"patch grid gives {patches.shape[0] // B} patches, config says {n_patches}")
-        wb, _ = WEIGHTS.get(conv_w, False)
+        wb, _ = WEIGHTS.get(conv_w, ctx.needs_input_grad[0])
         x = torch.empty((B * seq, D), dtype=F32, device=images.device)
         ops.gemm_nt(patches, wb, ops.EPI_PATCH_F32, bias=_f32c(conv_b), aux=_f32c(pos_w)[:n_patches].contiguous(), out=x,
                     n_patches=n_patches, seq=seq, extra=extra)
@@ -305,21 +305,34 @@ class PatchEmbedFn(torch.autograd.Function):
             x[:, :extra] = extra_w.detach().to(F32)  # learned extra tokens are PREPENDED (train_vit.py:43-44)
         if need_grad:
             ctx.save_for_backward(patches)
-        ctx.meta = (B, D, extra, seq, n_patches, tuple(conv_w.shape), pos_w.shape[0])
+            ctx.conv_w = conv_w
+        ctx.meta = (B, D, extra, seq, n_patches, tuple(conv_w.shape), pos_w.shape[0], tuple(images.shape), patch)
         return x
 
     @staticmethod
     def backward(ctx, g):
-        B, D, extra, seq, n_patches, wshape, pos_rows = ctx.meta
+        B, D, extra, seq, n_patches, wshape, pos_rows, ishape, patch = ctx.meta
         (patches,) = ctx.saved_tensors
         dpos, dextra, dyp, dbias = ops.embed_bwd(_f32c(g).view(B * seq, D), B, seq, extra, D)
-        dW = torch.zeros((D, patches.shape[1]), dtype=F32, device=g.device)
-        ops.gemm_tn(dyp, patches, dW)
+        dW = torch.empty((D, patches.shape[1]), dtype=F32, device=g.device)
+        ops.gemm_tn(dyp, patches, dW, accumulate=False)
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            # d(patches) = dY . W ; patches do not overlap, so the inverse gather is a pure permutation
+            _, wt = WEIGHTS.get(ctx.conv_w, True)
+            dpatch = ops.gemm_nt(dyp, wt, ops.EPI_BIAS_BF16)            # [B*np, C*p*p]
+            _, C, Hh, Ww = ishape
+            gh, gw = Hh // patch, Ww // patch
+            dimg = dpatch.view(B, gh, gw, C, patch, patch).permute(0, 3, 1, 4, 2, 5).reshape(B, C, gh * patch, gw * patch).to(F32)
+            if (gh * patch, gw * patch) != (Hh, Ww):
+                full = torch.zeros(ishape, dtype=F32, device=g.device)
+                full[:, :, : gh * patch, : gw * patch] = dimg
+                dimg = full
         if pos_rows != n_patches:
             full = torch.zeros((pos_rows, D), dtype=F32, device=g.device)
             full[:n_patches] = dpos
             dpos = full
-        return None, dW.view(wshape), dbias, dpos, dextra, None, None
+        return dimg, dW.view(wshape), dbias, dpos, dextra, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -330,36 +343,49 @@ def _pad64(n):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b through the MFMA GEMM; the output dim is zero-padded to a multiple of 64
-    internally so that it can serve as the reduction dim of the input-gradient GEMM."""
+    """y = x W^T + b through the MFMA GEMMs for arbitrary (small, odd) feature sizes: the output dim
+    is zero-padded to a multiple of 64 (it is the reduction dim of the input-gradient GEMM) and the
+    input dim likewise (reduction dim of the forward GEMM).  x: [M, K] -> [M, Nout] fp32."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         M, K = x.shape
         Nout = w.shape[0]
-        Np = _pad64(Nout)
+        Np, Kp = _pad64(Nout), _pad64(K)
         dev = x.device
-        wp = torch.zeros((Np, K), dtype=F32, device=dev)
-        wp[:Nout] = w.detach()
+        wp = torch.zeros((Np, Kp), dtype=F32, device=dev)
+        wp[:Nout, :K] = w.detach()
         bp = torch.zeros((Np,), dtype=F32, device=dev)
         if b is not None:
             bp[:Nout] = b.detach()
         wb, wbt = ops.cast_weight(wp, True, True)
-        xb = ops.cast_bf16(_f32c(x))
+        xf = _f32c(x)
+        if Kp != K:
+            xpad = torch.zeros((M, Kp), dtype=F32, device=dev)
+            xpad[:, :K] = xf
+            xf = xpad
+        xb = ops.cast_bf16(xf)
         y = ops.gemm_nt(xb, wb, ops.EPI_BIAS_BF16, bias=bp)
         ctx.save_for_backward(xb, wbt)
-        ctx.meta = (M, K, Nout, Np, x.dtype, b is not None)
+        ctx.meta = (M, K, Kp, Nout, Np, x.dtype, b is not None)
         return y[:, :Nout].to(F32)
 
     @staticmethod
     def backward(ctx, g):
-        M, K, Nout, Np, xdtype, has_b = ctx.meta
+        M, K, Kp, Nout, Np, xdtype, has_b = ctx.meta
         xb, wbt = ctx.saved_tensors
         gp = torch.zeros((M, Np), dtype=F32, device=g.device)
         gp[:, :Nout] = g
         gb = ops.cast_bf16(gp)
-        dx = ops.gemm_nt(gb, wbt, ops.EPI_BIAS_BF16)
-        dWp = torch.zeros((Np, K), dtype=F32, device=g.device)
-        ops.gemm_tn(gb, xb, dWp)
+        dx = ops.gemm_nt(gb, wbt, ops.EPI_BIAS_BF16) if ctx.needs_input_grad[0] else None
+        dWp = torch.empty((Np, Kp), dtype=F32, device=g.device)
+        ops.gemm_tn(gb, xb, dWp, accumulate=False)
         db = ops.colsum(gb)[:Nout].clone() if has_b else None
-        return dx.to(xdtype), dWp[:Nout].clone(), db
+        return (dx[:, :K].to(xdtype) if dx is not None else None), dWp[:Nout, :K].clone(), db
+
+
+def linear(x, weight, bias):
+    """nn.Linear semantics for any leading shape on the HIP path."""
+    lead = x.shape[:-1]
+    y = LinearFn.apply(x.reshape(-1, x.shape[-1]), weight.reshape(weight.shape[0], -1), bias)
+    return y.view(*lead, weight.shape[0])

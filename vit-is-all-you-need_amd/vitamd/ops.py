@@ -194,3 +194,15 @@ def embed_bwd(g, B, seq, extra, D):
     _lib.check(_L().vitamd_embed_bwd(_p(g), _p(dpos), _p(dextra) if extra > 0 else None, _p(dyp), _p(dbias), B, seq, extra, D,
                                      _stream()), "embed_bwd")
     return dpos, dextra, dyp, dbias
+
+
+def vq_nearest(x, codebook):
+    """x fp32 [M,d], codebook fp32 [K,d] -> int64 [M] index of the nearest code (first minimum)."""
+    _need(x, F32, "x", 2); _need(codebook, F32, "codebook", 2)
+    M, d = x.shape
+    K, d2 = codebook.shape
+    if d != d2:
+        raise _lib.VitamdError("vq_nearest: dim mismatch")
+    idx = torch.empty((M,), dtype=torch.int64, device=x.device)
+    _lib.check(_L().vitamd_vq_nearest(_p(x), _p(codebook), _p(idx), M, K, d, _stream()), "vq_nearest")
+    return idx
