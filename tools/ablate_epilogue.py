@@ -37,3 +37,13 @@ for tile in (2,):
     L.vitamd_set_debug(4)
     print(f"  resid: no load               {t(lambda: ops.gemm_nt(x, w, ops.EPI_RESID_F32, bias=bias, aux=res, tile=tile)):7.1f} us")
     L.vitamd_set_debug(0)
+
+print("non-temporal output stores (dbg bit 3):")
+for bits in (0, 8):
+    L.vitamd_set_debug(bits)
+    print(f"  dbg={bits}: bias {t(lambda: ops.gemm_nt(x, w, ops.EPI_BIAS_BF16, bias=bias, tile=2)):7.1f}  gelu {t(lambda: ops.gemm_nt(x, w, ops.EPI_GELU, bias=bias, tile=2)):7.1f}  dgelu {t(lambda: ops.gemm_nt(x, w, ops.EPI_DGELU, aux=pre, colsum=cs, tile=2)):7.1f} us")
+xk = rb(M, 4 * D); wk = rb(D, 4 * D, scale=0.03); b1 = torch.randn(D, device=dev); r1 = torch.randn(M, D, device=dev)
+for bits in (0, 8):
+    L.vitamd_set_debug(bits)
+    print(f"  dbg={bits}: fc2-shape plain {t(lambda: ops.gemm_nt(xk, wk, ops.EPI_BIAS_BF16, tile=2)):7.1f}  resid {t(lambda: ops.gemm_nt(xk, wk, ops.EPI_RESID_F32, bias=b1, aux=r1, tile=2)):7.1f} us")
+L.vitamd_set_debug(0)

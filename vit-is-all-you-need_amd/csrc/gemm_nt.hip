@@ -138,6 +138,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
 // a private 16-KiB LDS image ([128 rows][64 bf16], 16-B chunk index XOR (row&7)), after which a lane
 // owns 8 consecutive columns of one row: every global access is 16 B per lane and a wave-instruction
 // covers whole 128-B (bf16) / 256-B (fp32) row segments of 8 rows.
+// output stores are non-temporal (keeps the 32 MB-per-round output burst from evicting operand
+// panels out of the 8 x 4 MiB L2s: -5..7 % on the K = 3072 shapes); p.dbg bit 3 turns that off (A/B knob)
+#define ST16(ptr, val)                                              \
+  do {                                                              \
+    if (p.dbg & 8) *(ptr) = (val);                                  \
+    else __builtin_nontemporal_store((val), (ptr));                                            \
+  } while (0)
+
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn,
                                                    int lane, int tid, int wave, char* smem) {
@@ -214,14 +222,14 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
     const u32x4 v = *(const u32x4*)(tile + rloc * 128 + pc * 16);
     const bool ok = m < p.M && ncol_ok;
     if constexpr (EPI == EPI_BIAS_BF16) {
-      if (ok) *(u32x4*)((__bf16*)p.out + (size_t)m * ldo + n) = v;
+      if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
     } else if constexpr (EPI == EPI_GELU) {
       u32x4 a;
 #pragma unroll
       for (int c = 0; c < 4; ++c) a[c] = pack_bf16x2(gelu_fwd(bf16lo(v[c])), gelu_fwd(bf16hi(v[c])));
       if (ok) {
-        *(u32x4*)((__bf16*)p.out + (size_t)m * ldo + n) = v;
-        *(u32x4*)((__bf16*)p.out2 + (size_t)m * ldo + n) = a;
+        ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
+        ST16((u32x4*)((__bf16*)p.out2 + (size_t)m * ldo + n), a);
       }
     } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) {
       const f32x4 r0 = auxf[2 * it], r1 = auxf[2 * it + 1];
@@ -234,8 +242,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
       }
       if (ok) {
         float* op = (float*)p.out + orow * ldo + n;
-        *(f32x4*)op = o0;
-        *(f32x4*)(op + 4) = o1;
+        ST16((f32x4*)op, o0);
+        ST16((f32x4*)(op + 4), o1);
       }
     } else if constexpr (EPI == EPI_DGELU) {
       const u32x4 pz = auxb[it];
@@ -247,7 +255,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
         if (ok) { cs[2 * c] += lo; cs[2 * c + 1] += hi; }
         o[c] = pack_bf16x2(lo, hi);
       }
-      if (ok) *(u32x4*)((__bf16*)p.out + (size_t)m * ldo + n) = o;
+      if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), o);
     }
   }
   if constexpr (EPI == EPI_DGELU) {
@@ -744,9 +752,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
-  if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
+static int dispatch_epi(const GemmNtArgs& p, hipStream_t stream) {
   switch (p.epi) {
     case EPI_BIAS_BF16: return dispatch_tile<EPI_BIAS_BF16>(p, stream);
     case EPI_GELU: return p.out2 ? dispatch_tile<EPI_GELU>(p, stream) : VITAMD_ERR_ARG;
@@ -756,4 +762,37 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
     case EPI_F32: return dispatch_tile<EPI_F32>(p, stream);
     default: return VITAMD_ERR_ARG;
   }
+}
+
+int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
+  if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
+  // Tail split.  One 256x256 workgroup per CU means a launch runs in whole rounds of 256 tiles; a
+  // last round that is mostly empty (591 tiles = 2.31 rounds at N = 768) idles most of the chip for a
+  // full tile time.  When the remainder is under ~60 % of a round, the big kernel takes only the
+  // M-panels that fill whole rounds and the remaining rows go to the 128x128 kernel (2 workgroups
+  // per CU, quarter-size tiles), which finishes them in a fraction of a big-tile round.
+  constexpr int CUS = 256;
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const long big_tiles = (long)tiles_m * tiles_n;
+  const long rem = big_tiles % CUS;
+  if (p.tile == 0 && !(p.dbg & 16) && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
+    const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
+    const int rows_a = panels_a * 256;
+    if (panels_a > 0 && rows_a < p.M) {
+      GemmNtArgs a = p, b = p;
+      a.M = rows_a;
+      a.tile = 2;
+      const size_t esz_out = (p.epi == EPI_RESID_F32 || p.epi == EPI_F32) ? 4 : 2;
+      b.M = p.M - rows_a;
+      b.A = (const char*)p.A + (size_t)rows_a * p.K * 2;
+      b.out = (char*)p.out + (size_t)rows_a * p.ldo * esz_out;
+      if (p.out2) b.out2 = (char*)p.out2 + (size_t)rows_a * p.ldo * 2;
+      if (p.aux) b.aux = (const char*)p.aux + (size_t)rows_a * p.ldo * (p.epi == EPI_RESID_F32 ? 4 : 2);
+      b.tile = 128;
+      if (int e = dispatch_epi(a, stream)) return e;
+      return dispatch_epi(b, stream);
+    }
+  }
+  return dispatch_epi(p, stream);
 }
