@@ -70,7 +70,14 @@ def main():
     rec("gemm_tn wgrad fc1", timeit(lambda: ops.gemm_tn(x3072, x768, dW1)), 2 * M * D * 4 * D)
     dW2 = torch.zeros(D, 4 * D, device=dev)
     rec("gemm_tn wgrad fc2", timeit(lambda: ops.gemm_tn(x768, x3072, dW2)), 2 * M * D * 4 * D)
-    for sp in (4, 7, 14):
+    import ctypes
+    from vitamd import lib as _lib
+    _L = _lib.load(); _L.vitamd_set_debug.argtypes = [ctypes.c_int]
+    _L.vitamd_set_debug(64)
+    rec("gemm_tn wgrad qkv (16x16x32 variant)", timeit(lambda: ops.gemm_tn(x2304, x768, dW)), 2 * M * D * 3 * D)
+    rec("gemm_tn wgrad fc1 (16x16x32 variant)", timeit(lambda: ops.gemm_tn(x3072, x768, dW1)), 2 * M * D * 4 * D)
+    _L.vitamd_set_debug(0)
+    for sp in (7,):
         rec(f"gemm_tn wgrad fc1 splits={sp}", timeit(lambda: ops.gemm_tn(x3072, x768, dW1, splits=sp)), 2 * M * D * 4 * D)
 
     xf = torch.randn(M, D, device=dev)

@@ -80,3 +80,14 @@ if __name__ == "__main__":
         c = l >> 4
         return r * 64 + ((c ^ G4[(r >> 2) & 3]) << 4)
     print("NT BK=32 frag read swz / linear  :", b128([nt32(l, 0) for l in range(64)]), b128([(l & 15) * 64 + (l >> 4) * 16 for l in range(64)]))
+
+    # GEMM TN with 16x16x32 MFMA: [r][256 cols] tiles (512-B rows), chunk ^ (((r&3)<<2) | (((r>>3)&1)<<1))
+    def f16(r):
+        return ((r & 3) << 2) | (((r >> 3) & 1) << 1)
+
+    def tn16(l, hh, c0, ks):
+        g, qq, pp = l >> 4, (l >> 2) & 3, l & 3
+        r = 32 * ks + 8 * g + 4 * hh + qq
+        col = c0 + 4 * pp
+        return r * 512 + (((col >> 3) ^ f16(r)) << 4) + (col & 7) * 2
+    print("TN16 tr read b64   :", [b64([tn16(l, hh, c0, ks) for l in range(64)]) for hh in (0, 1) for c0 in (0, 16, 240) for ks in (0, 1)])

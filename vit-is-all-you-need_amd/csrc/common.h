@@ -75,6 +75,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// linear tile id -> (tile_m, tile_n).  Plain order walks N fastest.  Grouped order (wide N): blocks
+// of GROUP_M row panels x all N tiles, M fastest inside a block, so the ~32 tiles an XCD works on at a
+// time cover ~8 A panels x 4 B tiles (4.5 MB at K = 768) instead of 2.7 panels x 12 B tiles (5.6 MB,
+// re-fetching every weight tile from beyond L2 for each small group of panels).
+__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, bool grouped, int& tm, int& tn) {
+  constexpr int GROUP_M = 8;
+  if (!grouped) { tm = tile / tiles_n; tn = tile % tiles_n; return; }
+  const int per_group = GROUP_M * tiles_n;
+  const int g = tile / per_group, r = tile - g * per_group;
+  const int gm0 = g * GROUP_M;
+  const int gsz = min(GROUP_M, tiles_m - gm0);
+  tm = gm0 + r % gsz;
+  tn = r / gsz;
+}
+
 // bijective XCD-aware remap of a linear workgroup id: consecutive remapped ids share an XCD
 // (blocks b and b+8 share an XCD under round-robin dispatch).  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

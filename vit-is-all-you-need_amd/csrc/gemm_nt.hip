@@ -511,7 +511,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  int tm, tn;
+  tile_coords(tile, tiles_m, tiles_n, tiles_n >= 6 && !(p.dbg & 32), tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   const int K = p.K;
 
   const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(p.A, (size_t)p.M * K * 2);
