@@ -82,6 +82,10 @@ int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, cons
 int vitamd_cast_f32_bf16(const float* in, void* out_bf16, long n, void* stream);
 /* W fp32 [N,K] -> bf16 [N,K] (wb, may be NULL) and transposed bf16 [K,N] (wbt, may be NULL). */
 int vitamd_cast_transpose_weight(const float* w, void* wb, void* wbt, int N, int K, void* stream);
+/* The same for n weights in ONE launch.  desc_dev: device array of n records
+ * {const float* w; bf16* wb; bf16* wbt; int N, K, first_tile, tiles_k;} (40 bytes, 8-byte aligned),
+ * first_tile = running sum of ceil(N/64)*ceil(K/64), tiles_k = ceil(K/64); total_tiles = the final sum. */
+int vitamd_cast_transpose_batched(const void* desc_dev, int n, int total_tiles, void* stream);
 /* images fp32 [B,C,H,W] -> patches bf16 [B*(H/p)*(W/p), C*p*p], vector order (c,kh,kw): the
  * contraction order of Conv2d(kernel=stride=p), train_vit.py:34,39. */
 int vitamd_im2col_bf16(const float* img, void* out_bf16, int B, int C, int H, int W, int p, void* stream);

@@ -769,17 +769,20 @@ static int dispatch_epi(const GemmNtArgs& p, hipStream_t stream) {
 int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
   if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
-  // Tail split (OPT-IN: vitamd_set_debug bit 4).  One 256x256 workgroup per CU means a launch runs in
+  // Tail split.  One 256x256 workgroup per CU means a launch runs in
   // whole rounds of 256 tiles; a last round that is mostly empty (591 tiles = 2.31 rounds at N = 768)
   // idles most of the chip for a full tile time.  With the split, the big kernel takes only the
   // M-panels that fill whole rounds and the remaining rows go to the 128x128 kernel.  Measured: +5 % on
   // the isolated N = 768 GEMMs, but -0.5 ms on the whole step (tools/ab_step.py) because the weight-
-  // gradient GEMMs on the side stream already fill those tails; so it stays off by default.
+  // gradient GEMMs on the side stream already fill those tails in backward.
   constexpr int CUS = 256;
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const long big_tiles = (long)tiles_m * tiles_n;
   const long rem = big_tiles % CUS;
-  if (p.tile == 0 && (p.dbg & 16) && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
+  // on by default for the forward fc2 GEMM only (no side-stream filler runs in forward: -0.25 ms/step);
+  // bit 4 forces it everywhere, bit 7 turns it off
+  const bool split_on = (p.dbg & 16) || (!(p.dbg & 128) && p.epi == EPI_RESID_F32);
+  if (p.tile == 0 && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
     const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
     const int rows_a = panels_a * 256;
     if (panels_a > 0 && rows_a < p.M) {

@@ -39,6 +39,40 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
   }
 }
 
+// Batched form: one launch casts (and transposes) EVERY weight of the model.  desc[i] =
+// {w, wb, wbt, N, K, first_tile}; blockIdx.x walks the concatenated 64x64 tile lists.
+struct CastDesc { const float* w; __bf16* wb; __bf16* wbt; int N, K, first_tile, tiles_k; };
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastDesc* __restrict__ desc, int n) {
+  __shared__ float tile[64][65];
+  __shared__ int which;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n - 1;           // last descriptor whose first_tile <= blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    which = lo;
+  }
+  __syncthreads();
+  const CastDesc d = desc[which];
+  const int t = blockIdx.x - d.first_tile;
+  const int n0 = (t / d.tiles_k) * 64, k0 = (t % d.tiles_k) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int nn = n0 + r, k = k0 + tx;
+    float v = 0.f;
+    if (nn < d.N && k < d.K) {
+      v = d.w[(size_t)nn * d.K + k];
+      if (d.wb) d.wb[(size_t)nn * d.K + k] = f2bf(v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (d.wbt) {
+    for (int r = ty; r < 64; r += 4) {
+      const int k = k0 + r, nn = n0 + tx;
+      if (k < d.K && nn < d.N) d.wbt[(size_t)k * d.N + nn] = f2bf(tile[tx][r]);
+    }
+  }
+}
+
 // images fp32 [B,C,H,W] -> patches bf16 [B*gh*gw, C*p*p], patch vector order (c,kh,kw)
 // (the contraction order of Conv2d(kernel=stride=p), reference train_vit.py:34,39).  One thread per
 // 4 consecutive kw: 16-B fp32 loads along an image row, 8-B bf16 stores along the patch vector.
@@ -200,6 +234,13 @@ extern "C" int vitamd_cast_transpose_weight(const float* w, void* wb, void* wbt,
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
+extern "C" int vitamd_cast_transpose_batched(const void* desc_dev, int n, int total_tiles, void* stream) {
+  if (n <= 0 || total_tiles <= 0) return VITAMD_ERR_SHAPE;
+  if (!desc_dev) return VITAMD_ERR_ARG;
+  hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)desc_dev, n);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
 extern "C" int vitamd_im2col_bf16(const float* img, void* out_bf16, int B, int C, int H, int W, int p, void* stream) {
   if (B <= 0 || C <= 0 || p <= 0 || H < p || W < p) return VITAMD_ERR_SHAPE;
   if (!img || !out_bf16) return VITAMD_ERR_ARG;
@@ -234,7 +275,7 @@ extern "C" int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void
                                 int extra, int D, void* stream) {
   if (B <= 0 || seq <= 0 || extra < 0 || extra > seq || D <= 0) return VITAMD_ERR_SHAPE;
   if (!g || (seq > extra && (!dpos || !dyp_bf16 || !dbias)) || (extra > 0 && !dextra)) return VITAMD_ERR_ARG;
-  const int bchunk = 8;
+  const int bchunk = 32;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(seq, (B + bchunk - 1) / bchunk), dim3(256), 0, (hipStream_t)stream, g, dpos, dextra, (__bf16*)dyp_bf16, dbias, B, seq, extra, D, bchunk);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

@@ -15,31 +15,85 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 class WeightCache:
-    """bf16 (and transposed bf16) copies of fp32 parameters, refreshed when the parameter's
-    version counter changes (i.e. after every optimiser step) — autocast's per-step weight cast,
-    reference train_vit.py:100.  Entries are tied to the parameter OBJECT (weak reference), never
-    to its address: a freed parameter's storage may be handed to a different one."""
+    """bf16 (and transposed bf16) copies of fp32 parameters — autocast's per-step weight cast,
+    reference train_vit.py:100.  An entry is fresh while the parameter's version counter, storage
+    and the cache epoch are unchanged (`clear()` bumps the epoch: every optimiser step / bench step).
+    Entries are tied to the parameter OBJECT (weak reference), never to its address alone, and keep
+    their bf16 buffers across refreshes.  `prepare()` refreshes a whole list of weights with ONE
+    batched kernel launch instead of one launch per tensor."""
 
     def __init__(self):
         self._c = {}
-
-    def get(self, w: torch.Tensor, want_t: bool):
-        key = id(w)
-        ent = self._c.get(key)
-        ver = w._version
-        if ent is not None and ent[0]() is w and ent[1] == ver and ent[2] == w.data_ptr() and (ent[4] is not None or not want_t):
-            return ent[3], ent[4]
-        w2 = w.detach()
-        if w2.dim() != 2:
-            w2 = w2.reshape(w2.shape[0], -1)
-        wb, wbt = ops.cast_weight(w2.contiguous(), True, want_t)
-        if len(self._c) > 4096:
-            self._c = {k: v for k, v in self._c.items() if v[0]() is not None}
-        self._c[key] = (weakref.ref(w), ver, w.data_ptr(), wb, wbt)
-        return wb, wbt
+        self._groups = {}
+        self.epoch = 0
 
     def clear(self):
-        self._c.clear()
+        self.epoch += 1
+
+    def _fresh(self, ent, w, want_t):
+        return (ent is not None and ent["ref"]() is w and ent["ver"] == w._version and ent["ptr"] == w.data_ptr()
+                and ent["epoch"] == self.epoch and (ent["wbt"] is not None or not want_t))
+
+    @staticmethod
+    def _as2d(w):
+        w2 = w.detach()
+        return w2 if w2.dim() == 2 else w2.reshape(w2.shape[0], -1)
+
+    def _entry(self, w, want_t):
+        """entry with buffers allocated (contents possibly stale)"""
+        ent = self._c.get(id(w))
+        w2 = self._as2d(w)
+        if ent is None or ent["ref"]() is not w or ent["ptr"] != w.data_ptr() or tuple(ent["wb"].shape) != tuple(w2.shape):
+            if len(self._c) > 4096:
+                self._c = {k: v for k, v in self._c.items() if v["ref"]() is not None}
+                self._groups.clear()
+            ent = self._c[id(w)] = {"ref": weakref.ref(w), "ver": -1, "ptr": w.data_ptr(), "epoch": -1,
+                                    "wb": torch.empty(w2.shape, dtype=BF16, device=w.device), "wbt": None}
+        if want_t and ent["wbt"] is None:
+            ent["wbt"] = torch.empty((w2.shape[1], w2.shape[0]), dtype=BF16, device=w.device)
+            ent["ver"] = -1
+        return ent
+
+    def get(self, w: torch.Tensor, want_t: bool):
+        ent = self._c.get(id(w))
+        if self._fresh(ent, w, want_t):
+            return ent["wb"], ent["wbt"]
+        ent = self._entry(w, want_t)
+        w2 = self._as2d(w).contiguous()
+        N, K = w2.shape
+        ops._lib.check(ops._L().vitamd_cast_transpose_weight(w2.data_ptr(), ent["wb"].data_ptr(),
+                                                             ent["wbt"].data_ptr() if ent["wbt"] is not None else None, N, K,
+                                                             ops._stream()), "cast_transpose_weight")
+        ent["ver"], ent["epoch"] = w._version, self.epoch
+        return ent["wb"], ent["wbt"]
+
+    def prepare(self, weights, want_t: bool):
+        """make every weight in the list fresh with one batched launch (no-op when they all are)"""
+        if all(self._fresh(self._c.get(id(w)), w, want_t) for w in weights):
+            return
+        import numpy as np
+        ents = [self._entry(w, want_t) for w in weights]
+        key = (tuple(id(w) for w in weights), want_t)
+        grp = self._groups.get(key)
+        sig = tuple((e["ptr"], e["wb"].data_ptr(), e["wbt"].data_ptr() if e["wbt"] is not None else 0) for e in ents)
+        if grp is None or grp["sig"] != sig or any(not w.is_contiguous() for w in weights):
+            if any(not w.is_contiguous() for w in weights):
+                for w in weights:
+                    self.get(w, want_t)
+                return
+            dt = np.dtype([("w", "<u8"), ("wb", "<u8"), ("wbt", "<u8"), ("N", "<i4"), ("K", "<i4"), ("first", "<i4"), ("tk", "<i4")])
+            tab = np.zeros(len(weights), dtype=dt)
+            first = 0
+            for i, (w, e) in enumerate(zip(weights, ents)):
+                N, K = e["wb"].shape
+                tab[i] = (e["ptr"], sig[i][1], sig[i][2], N, K, first, (K + 63) // 64)
+                first += ((N + 63) // 64) * ((K + 63) // 64)
+            dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(weights[0].device)
+            grp = self._groups[key] = {"sig": sig, "table": dev_tab, "tiles": first}
+        ops._lib.check(ops._L().vitamd_cast_transpose_batched(grp["table"].data_ptr(), len(weights), grp["tiles"], ops._stream()),
+                       "cast_transpose_batched")
+        for w, e in zip(weights, ents):
+            e["ver"], e["epoch"] = w._version, self.epoch
 
 
 WEIGHTS = WeightCache()
@@ -215,6 +269,7 @@ class TransformerStackFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         cur = _f32c(x).view(B * N, D)
         saved_all = []
+        WEIGHTS.prepare([params[6 * i + j] for i in range(L) for j in (0, 2, 4)], need_grad)
         for i in range(L):
             wqkv, bqkv, w1, b1, w2, b2 = params[6 * i: 6 * i + 6]
             cur, saved = layer_forward(cur, wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads, causal, need_grad)

@@ -30,6 +30,7 @@ SIGNATURES = {
     "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vitamd_cast_f32_bf16": [_P, _P, _L, _P],
     "vitamd_cast_transpose_weight": [_P, _P, _P, _I, _I, _P],
+    "vitamd_cast_transpose_batched": [_P, _I, _I, _P],
     "vitamd_im2col_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "vitamd_colsum_bf16": [_P, _P, _I, _I, _I, _P],
     "vitamd_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
