@@ -263,3 +263,29 @@ def test_tokenizer_vs_reference_golden(hip, name):
         if e > 3 * floor["grads"][k] + 2e-2:
             bad.append((k, round(e, 4), round(floor["grads"][k], 4)))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("preset,seq,batch", [("L", 65, 2), ("S", 288, 2), ("B", 256, 1)])
+def test_single_layer_presets_vs_oracle(hip, preset, seq, batch):
+    """One layer of each reference preset (transformer.py:56-58) at the sequence lengths the tokenizers
+    use (288 = TiTok, 256 = ViT-VQGAN) against the oracle's bf16-flow emulation."""
+    import transformer as T
+    L_, H, D = O.PRESETS[preset]
+    sd = W.transformer_state(40 + seq, "", 1, D)
+    cfg = T.TransformerConfig(n_layers=1, n_heads=H, n_embd=D, block_size=seq)
+    m = T.Transformer(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = W.normal(40 + seq, "x", (batch, seq, D))
+    dy = W.normal(40 + seq, "dy", (batch, seq, D))
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    (y * dy.cuda()).sum().backward()
+    xo = x.clone().requires_grad_(True)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = O.transformer(xo, leaves, "", 1, H, False, lowp=True)
+    go = torch.autograd.grad((yo * dy).sum(), [xo] + list(leaves.values()))
+    assert O.rel_l2(y.detach().cpu(), yo.detach()) < 4e-3
+    assert O.rel_l2(xg.grad.cpu(), go[0]) < 1e-2
+    for (k, p), gk in zip(m.named_parameters(), go[1:]):
+        assert O.rel_l2(p.grad.cpu(), gk) < 1.5e-2, k
