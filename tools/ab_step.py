@@ -17,7 +17,7 @@ def measure(n=6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-variants = {"default": (0, True), "tail split fwd fc2 only": (128, True), "tail split all": (16, True)}
+variants = {"default": (0, True), "no stagger": (255 << 8, True), "stagger 12": (12 << 8, True), "no fc2 tail split": (128, True)}
 for _ in range(3): step()
 res = {k: [] for k in variants}
 for rnd in range(4):

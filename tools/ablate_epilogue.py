@@ -47,3 +47,9 @@ for bits in (0, 8):
     L.vitamd_set_debug(bits)
     print(f"  dbg={bits}: fc2-shape plain {t(lambda: ops.gemm_nt(xk, wk, ops.EPI_BIAS_BF16, tile=2)):7.1f}  resid {t(lambda: ops.gemm_nt(xk, wk, ops.EPI_RESID_F32, bias=b1, aux=r1, tile=2)):7.1f} us")
 L.vitamd_set_debug(0)
+
+print("phase stagger of odd first-round workgroups (dbg bits 8..15, ~1 us units):")
+for st in (0, 4, 8, 12, 16, 24):
+    L.vitamd_set_debug(st << 8)
+    print(f"  stagger {st:2d}: qkv-like bias {t(lambda: ops.gemm_nt(x, w, ops.EPI_BIAS_BF16, bias=bias, tile=2)):7.1f}  gelu {t(lambda: ops.gemm_nt(x, w, ops.EPI_GELU, bias=bias, tile=2)):7.1f}  dgelu {t(lambda: ops.gemm_nt(x, w, ops.EPI_DGELU, aux=pre, colsum=cs, tile=2)):7.1f}  fc2 resid {t(lambda: ops.gemm_nt(xk, wk, ops.EPI_RESID_F32, bias=b1, aux=r1, tile=2)):7.1f} us")
+L.vitamd_set_debug(0)

@@ -539,6 +539,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
   const int b_off = BM * 128 + wn * WTN * 128 + frag_off;
   const int nkt = K / 64;
 
+  // Phase stagger: the odd workgroups of the FIRST round start ~8 us late, so that from then on the
+  // two halves of the chip reach their HBM-bound epilogues at different times (successor workgroups
+  // inherit the offset).  Measured -3..-7 % per GEMM (tools/ablate_epilogue.py).  dbg bits 8..15
+  // override the delay in ~1 us units (255 = off).
+  {
+    const int req = (p.dbg >> 8) & 0xff;
+    const int st = req == 255 ? 0 : (req ? req : 8);
+    if (st && gridDim.x > 256 && blockIdx.x < 256 && (blockIdx.x & 1)) {
+      for (int i = 0; i < st; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   {  // prologue: whole tile 0
     char* base = smem + wave * 1024;
 #pragma unroll

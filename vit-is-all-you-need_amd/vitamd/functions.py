@@ -296,10 +296,10 @@ class TransformerStackFn(torch.autograd.Function):
             nxt_db2 = arena[i - 1][5] if i > 0 else None      # layer i's first LN backward feeds layer i-1's fc2 bias grad
             cur, dy2 = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal, arena[i],
                                       dy2=dy2, have_db2=dy2 is not None, emit_bf16=i > 0, emit_colsum=nxt_db2)
-            if sink is not None and i + 1 < L:
-                sink.layer_ready(params, i + 1)   # layer i+1's bucket is complete once layer i's LN1 backward added its db2
-        if sink is not None:
-            sink.layer_ready(params, 0)
+            if sink is not None:
+                # bucket i is complete now: five gradients from this call, and its fc2 bias gradient was
+                # added by layer i+1's LN1 backward (or by this call's own column sum for the top layer)
+                sink.layer_ready(params, i)
         join_side(cur.device)
         grads = [t for layer in arena for t in layer]
         return (cur.view(B, N, D).to(xdtype), None, None, *grads)
