@@ -37,6 +37,7 @@ def r16(x):
                                         (256, 128, 32, 1), (512, 768, 768, 1), (1000, 2304, 96, 1), (333, 200, 160, 1),
                                         (197 * 64, 768, 3072, 0), (197 * 64, 3072, 768, 0), (50432, 2304, 768, 0),
                                         (256, 256, 32, 4), (512, 768, 768, 4), (1000, 2304, 96, 3), (333, 200, 160, 5), (197 * 64, 768, 3072, 4), (256, 256, 64, 5),
+                                        (256, 256, 64, 6), (512, 768, 768, 6), (1000, 2304, 128, 6), (333, 200, 192, 6), (197 * 64, 768, 3072, 6), (50432, 768, 768, 6),
                                         (256, 256, 64, 2), (512, 768, 768, 2), (1000, 2304, 128, 2), (333, 200, 192, 2), (197 * 64, 768, 3072, 2)])
 def test_gemm_nt_exact_integers(hip, M, N, K, tile):
     from vitamd import ops
@@ -48,7 +49,7 @@ def test_gemm_nt_exact_integers(hip, M, N, K, tile):
     assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 128, 256])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 128, 256])
 def test_gemm_nt_epilogues(hip, tile):
     import functools
     from vitamd import ops as _ops

@@ -17,6 +17,7 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-for name, a, b in (("K=768 N=2304", x768, wqkv), ("K=3072 N=768", x3072, w2)):
-    for tile, what in ((2, "pipe full"), (21, "pipe no MFMA"), (22, "pipe no LDS-DMA"), (3, "deep ring 3"), (4, "deep ring 4"), (5, "deep ring 5"), (256, "old burst kernel")):
+w1 = rb(4 * D, D, scale=0.03)
+for name, a, b in (("K=768 N=2304", x768, wqkv), ("K=768 N=3072", x768, w1), ("K=3072 N=768", x3072, w2)):
+    for tile, what in ((2, "pipe"), (6, "persistent"), (2, "pipe"), (6, "persistent")):
         print(f"{name:14s} {what:18s} {t(lambda: ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, tile=tile)):8.1f} us", flush=True)

@@ -14,7 +14,7 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
                                    float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
                                    int tile, void* stream) {
   GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug};
-  if (!(tile >= 0 && tile <= 5) && tile != 128 && tile != 256 && (tile < 21 || tile > 23)) return VITAMD_ERR_ARG;
+  if (!(tile >= 0 && tile <= 6) && tile != 128 && tile != 256 && (tile < 21 || tile > 24)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }
 

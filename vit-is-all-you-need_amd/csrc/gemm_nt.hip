@@ -583,12 +583,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) if (ABL != 3 || kt == 0) bq[1][j] = *(const bf16x8*)(buf + ((b_off + j * 2048) ^ 64));
       }
+      if constexpr (ABL == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           if constexpr (ABL == 1) { asm volatile("" ::"v"(bq[ks][j]), "v"(aq[g & 1][i])); }
           else acc[2 * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[g & 1][i], acc[2 * pr + i][j], 0, 0, 0);
+      if constexpr (ABL == 4) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -721,6 +723,278 @@ int launch_deep(const GemmNtArgs& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the pipe kernel: one workgroup per CU walks a strided list of tiles.  The
+// LDS-DMA of the NEXT tile's first K-tile is issued during the current tile's last K-step, so the
+// per-tile prologue (launch gap, descriptor setup, first DMA round trip: ~4 of ~27 us at K = 768)
+// disappears, and the epilogue's global stores are still draining while the next main loop starts
+// (its first wait is a COUNTED vmcnt that skips the younger stores).  The epilogue transposes through
+// the ONE operand buffer that is free at that point (64 KiB: two passes of 64 rows per wave).
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows_halves(const GemmNtArgs& p, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn,
+                                                     int lane, int tid, int wave, char* scratch /* 64 KiB, free */) {
+  constexpr int BN = 256;
+  char* tile = scratch + wave * 8192;     // wave-private image: 64 rows x 128 B
+  const int mloc = lane & 15, g = lane >> 4;
+  const int ncol_acc = n0 + wn * 64 + 4 * g;
+  const int rsub = lane >> 3, pc = lane & 7;
+  const int ldo = p.ldo;
+  const int n = n0 + wn * 64 + 8 * (pc ^ rsub);
+  const bool ncol_ok = n < p.N;
+  const int nc = ncol_ok ? n : 0;
+  float cs[8];
+  if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cs[c] = 0.f;
+  }
+  f32x4 bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI != EPI_DGELU) {
+      const int nb = ncol_acc + j * 16;
+      if (p.bias && nb < p.N) {
+        const f32x4 b = *(const f32x4*)(p.bias + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[j][r] = round_bf16(b[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int mbase = m0 + wm * 128 + 64 * half + rsub;
+    // auxiliary loads of this half first (latency overlaps the LDS round trip)
+    u32x4 auxb[EPI == EPI_DGELU ? 8 : 1];
+    f32x4 auxf[(EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) ? 16 : 1];
+    if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) auxb[it] = *(const u32x4*)((const __bf16*)p.aux + (size_t)min(mbase + 8 * it, p.M - 1) * ldo + nc);
+    } else if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const float* rp = (const float*)p.aux + (size_t)min(mbase + 8 * it, p.M - 1) * ldo + nc;
+        auxf[2 * it] = *(const f32x4*)rp;
+        auxf[2 * it + 1] = *(const f32x4*)(rp + 4);
+      }
+    } else if constexpr (EPI == EPI_PATCH_F32) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const float* pp = (const float*)p.aux + (size_t)(min(mbase + 8 * it, p.M - 1) % p.n_patches) * ldo + nc;
+        auxf[2 * it] = *(const f32x4*)pp;
+        auxf[2 * it + 1] = *(const f32x4*)(pp + 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 v = acc[4 * half + i][j] + bias4[j];
+        const int row = 16 * i + mloc;
+        const int chunk = (2 * j + (g >> 1)) ^ (row & 7);
+        u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(u32x2*)(tile + row * 128 + (chunk << 4) + (g & 1) * 8) = o;
+      }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rloc = rsub + 8 * it;
+      const int m = mbase + 8 * it;
+      const u32x4 v = *(const u32x4*)(tile + rloc * 128 + pc * 16);
+      const bool ok = m < p.M && ncol_ok;
+      if constexpr (EPI == EPI_BIAS_BF16) {
+        if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
+      } else if constexpr (EPI == EPI_GELU) {
+        u32x4 a;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = pack_bf16x2(gelu_fwd(bf16lo(v[c])), gelu_fwd(bf16hi(v[c])));
+        if (ok) {
+          ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
+          ST16((u32x4*)((__bf16*)p.out2 + (size_t)m * ldo + n), a);
+        }
+      } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) {
+        const f32x4 r0 = auxf[2 * it], r1 = auxf[2 * it + 1];
+        f32x4 o0 = {r0[0] + bf16lo(v[0]), r0[1] + bf16hi(v[0]), r0[2] + bf16lo(v[1]), r0[3] + bf16hi(v[1])};
+        f32x4 o1 = {r1[0] + bf16lo(v[2]), r1[1] + bf16hi(v[2]), r1[2] + bf16lo(v[3]), r1[3] + bf16hi(v[3])};
+        size_t orow = (size_t)m;
+        if constexpr (EPI == EPI_PATCH_F32) {
+          const int b = m / p.n_patches, pidx = m - b * p.n_patches;
+          orow = (size_t)b * p.seq + p.extra + pidx;
+        }
+        if (ok) {
+          float* op = (float*)p.out + orow * ldo + n;
+          ST16((f32x4*)op, o0);
+          ST16((f32x4*)(op + 4), o1);
+        }
+      } else if constexpr (EPI == EPI_DGELU) {
+        const u32x4 pz = auxb[it];
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float lo = round_bf16(bf16lo(v[c]) * gelu_grad(bf16lo(pz[c])));
+          const float hi = round_bf16(bf16hi(v[c]) * gelu_grad(bf16hi(pz[c])));
+          if (ok) { cs[2 * c] += lo; cs[2 * c + 1] += hi; }
+          o[c] = pack_bf16x2(lo, hi);
+        }
+        if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), o);
+      }
+    }
+  }
+  if constexpr (EPI == EPI_DGELU) {
+    if (p.colsum) {
+      __syncthreads();                   // every wave finished with its image
+      float* red = (float*)scratch;      // [8 waves][8 rsub][64 cols] floats = 16 KiB
+      float* mine = red + (wave * 8 + rsub) * 64 + 8 * (pc ^ rsub);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) mine[c] = cs[c];
+      __syncthreads();
+      for (int c = tid; c < BN; c += 512) {
+        const int wnn = c >> 6, cc = c & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) s += red[((w * 4 + wnn) * 8 + r) * 64 + cc];
+        if (n0 + c < p.N) atomicAdd(p.colsum + n0 + c, s);
+      }
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const GemmNtArgs p) {
+  constexpr int BM = 256, BN = 256, WN = 4, NW = 8;
+  constexpr int MT = 8, NT = 4, PPW = 8;
+  constexpr int BUF_BYTES = (BM + BN) * 128;
+  // younger VMEM ops (epilogue stores) guaranteed per lane after the next tile's first DMA, for FULL tiles
+  constexpr int EPI_STORES = (EPI == EPI_BIAS_BF16 || EPI == EPI_DGELU) ? 16 : 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const bool grouped = tiles_n >= 6 && !(p.dbg & 32);
+  const int K = p.K;
+  const int nkt = K / 64;
+  const __amdgpu_buffer_rsrc_t rsrcA = make_rsrc(p.A, (size_t)p.M * K * 2);
+  const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(p.B, (size_t)p.N * K * 2);
+  const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7)) & 7) << 4);
+  const int a_off = wm * 128 * 128 + frag_off;
+  const int b_off = BM * 128 + wn * 64 * 128 + frag_off;
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    int tm, tn;
+    tile_coords(xcd_remap(t, ntiles), tiles_m, tiles_n, grouped, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+  auto make_voff = [&](int m0, int n0, unsigned (&voff)[PPW]) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = (i * NW + wave) * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ (row & 7);
+      const int grow = (i < 4) ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);
+      voff[i] = (unsigned)grow * (unsigned)(K * 2) + logical * 16;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  int m0, n0;
+  tile_origin(t, m0, n0);
+  unsigned voff[PPW];
+  make_voff(m0, n0, voff);
+  int par = 0;                                   // LDS buffer of this tile's K-tile 0
+  {
+    char* base = smem + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) buf_glds16(i < 4 ? rsrcA : rsrcB, base + i * NW * 1024, voff[i], 0);
+  }
+  bool counted_wait = false;                     // first wait of a tile may skip the previous tile's stores
+  while (true) {
+    const int tnext = t + gridDim.x;
+    const bool has_next = tnext < ntiles;
+    int m0n = 0, n0n = 0;
+    if (has_next) tile_origin(tnext, m0n, n0n);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int cur = (par + kt) & 1;
+      if (kt == 0 && counted_wait) {
+        if constexpr (EPI_STORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* buf = smem + cur * BUF_BYTES;
+      char* nbase = smem + (cur ^ 1) * BUF_BYTES + wave * 1024;
+      const bool last = kt + 1 == nkt;
+      const bool more = !last || has_next;
+      if (last && has_next) make_voff(m0n, n0n, voff);     // the prefetch now targets the next tile's K-tile 0
+      const int soff = last ? 0 : (kt + 1) * 128;
+
+      bf16x8 bq[2][NT], aq[2][2];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bq[0][j] = *(const bf16x8*)(buf + b_off + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) aq[0][i] = *(const bf16x8*)(buf + a_off + i * 2048);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int ks = g >> 2, pr = g & 3;
+        if (more) buf_glds16(g < 4 ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
+        if (g < 7) {
+          const int ks2 = (g + 1) >> 2, pr2 = (g + 1) & 3;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) aq[(g + 1) & 1][i] = *(const bf16x8*)(buf + ((a_off + (2 * pr2 + i) * 2048) ^ (ks2 * 64)));
+        }
+        if (g == 1) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bq[1][j] = *(const bf16x8*)(buf + ((b_off + j * 2048) ^ 64));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[2 * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[g & 1][i], acc[2 * pr + i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the last K-tile was read from buffer (par + nkt - 1) & 1; the other one is receiving the next tile
+    const int last_buf = (par + nkt - 1) & 1;
+    __syncthreads();                              // all waves done reading last_buf (plain barrier: may drain DMA, harmless)
+    epilogue_rows_halves<EPI>(p, acc, m0, n0, wm, wn, lane, tid, wave, smem + last_buf * BUF_BYTES);
+    if (!has_next) break;
+    // a FULL tile issued exactly EPI_STORES stores per lane after the DMA: its landing can be waited for
+    // with a counted vmcnt; a partial tile issued fewer, so fall back to vmcnt(0)
+    counted_wait = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (EPI != EPI_DGELU || p.colsum == nullptr);
+    par = last_buf ^ 1;
+    t = tnext;
+    m0 = m0n;
+    n0 = n0n;
+  }
+}
+
+template <int EPI>
+int launch_persist(const GemmNtArgs& p, hipStream_t stream) {
+  constexpr int lds = 2 * 512 * 128;
+  auto kern = gemm_nt_persist_kernel<EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return VITAMD_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(512), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 int launch(const GemmNtArgs& p, hipStream_t stream) {
   constexpr int lds = 2 * (BM + BN) * 128;
@@ -750,6 +1024,9 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   }
   if (tile == 1) return ring_ok ? launch_ring<256, 128, 2, 2, EPI>(p, stream) : VITAMD_ERR_SHAPE;
   if (tile == 2) return (ring_ok && p.K % 64 == 0) ? launch_pipe<EPI>(p, stream) : VITAMD_ERR_SHAPE;
+  if constexpr (EPI != EPI_F32) {
+    if (tile == 6) return (ring_ok && p.K % 64 == 0 && p.N % 8 == 0 && p.ldo % 8 == 0) ? launch_persist<EPI>(p, stream) : VITAMD_ERR_SHAPE;
+  }
   if (tile == 3) return ring_ok ? launch_deep<EPI, 3>(p, stream) : VITAMD_ERR_SHAPE;
   if (tile == 4) return ring_ok ? launch_deep<EPI, 4>(p, stream) : VITAMD_ERR_SHAPE;
   if (tile == 5) return ring_ok ? launch_deep<EPI, 5>(p, stream) : VITAMD_ERR_SHAPE;
@@ -757,6 +1034,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
     if (tile == 21) return launch_pipe<EPI, 1>(p, stream);
     if (tile == 22) return launch_pipe<EPI, 2>(p, stream);
     if (tile == 23) return launch_pipe<EPI, 3>(p, stream);
+    if (tile == 24) return launch_pipe<EPI, 4>(p, stream);   // s_setprio(1) around every MFMA group
   }
   if (p.K % BK != 0) return VITAMD_ERR_SHAPE;
   if (tile == 256) return launch<256, 256, 2, 4, EPI>(p, stream);
