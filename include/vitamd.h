@@ -73,9 +73,10 @@ int vitamd_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean,
  * mask of transformer.py:22-25.   replaces transformer.py:27-29 (rearrange + SDPA + rearrange). */
 int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal,
                          void* stream);
-/* dqkv bf16 [B,N,3,H,64]; delta fp32 [B,H,N] is scratch written by the call. */
+/* dqkv bf16 [B,N,3,H,64]; delta fp32 [B,H,N] is scratch written by the call; dbias (may be NULL) fp32
+ * [3*H*64]: the column sums of dqkv (= gradient of the QKV bias, transformer.py:21) are ADDED to it. */
 int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, const void* d_o, void* dqkv,
-                         float* delta, int B, int N, int H, int head_dim, int causal, void* stream);
+                         float* delta, float* dbias, int B, int N, int H, int head_dim, int causal, void* stream);
 
 /* ---- helpers around the GEMMs ---------------------------------------------------------------- */
 /* fp32 -> bf16 (autocast's per-step weight / activation cast, train_vit.py:100). */

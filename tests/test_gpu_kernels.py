@@ -179,7 +179,9 @@ def test_attention_fwd_bwd(hip, B, N, H, causal):
     if causal:
         s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
     assert O.rel_l2(lse.cpu(), torch.logsumexp(s, -1) / math.log(2.0)) < 1e-4
-    dqkv = ops.attention_bwd(qd, o, lse, d_o.to(dev(), BF16), B, N, H, causal).float().cpu()
+    dbias = torch.full((3 * H * 64,), 1.0, device=dev())
+    dqkv = ops.attention_bwd(qd, o, lse, d_o.to(dev(), BF16), B, N, H, causal, dbias=dbias).float().cpu()
+    assert O.rel_l2(dbias.cpu() - 1.0, dqkv.sum(0)) < 2e-4     # fused QKV-bias gradient = column sums of what was stored
     D = H * 64
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 1.2e-2, name

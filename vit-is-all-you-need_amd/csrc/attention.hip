@@ -104,7 +104,7 @@ __device__ __forceinline__ void store_rows_T(__bf16* __restrict__ g, int ld, int
 // and a wave-instruction covers 8 whole 128-B head rows (4 store instructions instead of 16
 // scattered 8-B ones: the output tail was store-issue bound).
 __device__ __forceinline__ void store_rows_T_lds(__bf16* __restrict__ g, int ld, int N, int r0, int lane, const f32x16 (&acc)[2],
-                                                 float scale, char* img) {
+                                                 float scale, char* img, float* colacc = nullptr) {
   const int rr = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -122,6 +122,15 @@ __device__ __forceinline__ void store_rows_T_lds(__bf16* __restrict__ g, int ld,
     const u32x4 v = *(const u32x4*)(img + row * 128 + pc * 16);
     if (r0 + row < N) *(u32x4*)(g + (size_t)(r0 + row) * ld + 8 * (pc ^ (row & 7))) = v;
   }
+  if (colacc) {
+    // column sums of the stored bf16 rows (the bias gradient of the QKV Linear): lane = column
+    const int chunk = lane >> 3, within = (lane & 7) * 2;
+    const int nrows = min(32, N - r0);
+    float sacc = 0.f;
+    for (int row = 0; row < nrows; ++row)
+      sacc += bf2f(*(const __bf16*)(img + row * 128 + ((chunk ^ (row & 7)) << 4) + within));
+    *colacc += sacc;
+  }
 }
 
 struct AttnArgs {
@@ -131,6 +140,7 @@ struct AttnArgs {
   const __bf16* d_o;   // bwd: [B, N, H*64]
   __bf16* dqkv;        // bwd: [B, N, 3, H, 64]
   float* delta;        // bwd: [B, H, N] rowsum(dO o O)
+  float* dbias;        // bwd: optional [3*H*64] fp32, column sums of dqkv are ADDED (QKV bias gradient)
   int B, N, H;
   int causal;
   float scale_log2e;   // (1/sqrt(dh)) * log2(e)
@@ -308,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   const float c = a.scale_log2e;
   const __bf16* obase = a.o + (size_t)b * N * D + hh * DH;
   const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  float csum_q = 0.f;
   for (int qb = (wave + blockIdx.x) & 3; qb < nt; qb += 4) {
     const int q0 = qb * 32;
     const int qrow = q0 + (lane & 31);
@@ -360,8 +371,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ktile, T, sidx, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    store_rows_T_lds(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale, oimg);
+    store_rows_T_lds(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale, oimg, a.dbias ? &csum_q : nullptr);
   }
+  if (a.dbias) atomicAdd(a.dbias + hh * DH + lane, csum_q);   // 256 contiguous bytes per wave
 }
 
 // ------------------------------------------------------------------------------------------ backward, dK and dV
@@ -389,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
   __syncthreads();
 
   const float c = a.scale_log2e;
+  float csum_k = 0.f, csum_v = 0.f;
   for (int kb = (wave + blockIdx.x) & 3; kb < nt; kb += 4) {
     const int k0 = kb * 32;
     const int krow = k0 + (lane & 31);
@@ -443,8 +456,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
       }
     }
     __bf16* dbase = a.dqkv + (size_t)b * N * D3 + hh * DH;
-    store_rows_T_lds(dbase + D, D3, N, k0, lane, dk, a.scale, oimg);
-    store_rows_T_lds(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f, oimg);
+    store_rows_T_lds(dbase + D, D3, N, k0, lane, dk, a.scale, oimg, a.dbias ? &csum_k : nullptr);
+    store_rows_T_lds(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f, oimg, a.dbias ? &csum_v : nullptr);
+  }
+  if (a.dbias) {
+    atomicAdd(a.dbias + D + hh * DH + lane, csum_k);
+    atomicAdd(a.dbias + 2 * D + hh * DH + lane, csum_v);
   }
 }
 
@@ -462,7 +479,7 @@ int set_lds(K kern, int bytes) {
 
 extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal, void* stream) {
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
-  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f};
+  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2) return VITAMD_ERR_ARG;
   const int nkt = (N + 31) / 32, npad = nkt * 32;
@@ -484,9 +501,9 @@ extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B
 }
 
 extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, const void* d_o, void* dqkv, float* delta,
-                                    int B, int N, int H, int head_dim, int causal, void* stream) {
+                                    float* dbias, int B, int N, int H, int head_dim, int causal, void* stream) {
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
-  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, (float*)lse2, (const __bf16*)d_o, (__bf16*)dqkv, delta, B, N, H, causal,
+  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, (float*)lse2, (const __bf16*)d_o, (__bf16*)dqkv, delta, dbias, B, N, H, causal,
              0.125f * 1.4426950408889634f, 0.125f};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta) return VITAMD_ERR_ARG;

@@ -215,12 +215,8 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True)
     # ---- attention
-    dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal)
-
-    def wgrad_qkv():
-        ops.gemm_tn(dqkv, a, dWqkv, accumulate=False)
-        ops.colsum(dqkv, dbqkv)
-    on_side(wgrad_qkv, dqkv, a, dWqkv, dbqkv)
+    dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=dbqkv)    # also adds the QKV bias gradient
+    on_side(lambda: ops.gemm_tn(dqkv, a, dWqkv, accumulate=False), dqkv, a, dWqkv)
     da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
     g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum)
     return g0, g0b
@@ -329,10 +325,10 @@ class AttentionFn(torch.autograd.Function):
         xb, qkv, o, lse = ctx.saved_tensors
         _, wt = WEIGHTS.get(ctx.wqkv, True)
         d_o = ops.cast_bf16(_f32c(g).view(B * N, D))
-        dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal)
+        db = torch.zeros((3 * D,), dtype=F32, device=g.device)
+        dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=db)
         dW = torch.empty((3 * D, D), dtype=F32, device=g.device)
         ops.gemm_tn(dqkv, xb, dW, accumulate=False)
-        db = ops.colsum(dqkv)
         dx = ops.gemm_nt(dqkv, wt, ops.EPI_BIAS_BF16)
         return dx.view(B, N, D).to(xdtype), dW, db, None, None
 

@@ -138,11 +138,15 @@ def attention_fwd(qkv, B, N, H, causal=False):
     return o, lse
 
 
-def attention_bwd(qkv, o, lse, d_o, B, N, H, causal=False):
+def attention_bwd(qkv, o, lse, d_o, B, N, H, causal=False, dbias=None):
+    """dqkv bf16 [B*N, 3*H*64]; the column sums of dqkv (QKV bias gradient) are added to `dbias` if given."""
     _need(qkv, BF16, "qkv", 2); _need(o, BF16, "o", 2); _need(d_o, BF16, "d_o", 2); _need(lse, F32, "lse")
+    if dbias is not None:
+        _need(dbias, F32, "dbias", 1)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    code = _L().vitamd_attention_bwd(_p(qkv), _p(o), _p(lse), _p(d_o), _p(dqkv), _p(delta), B, N, H, 64, int(causal), _stream())
+    code = _L().vitamd_attention_bwd(_p(qkv), _p(o), _p(lse), _p(d_o), _p(dqkv), _p(delta), _p(dbias), B, N, H, 64, int(causal),
+                                     _stream())
     _lib.check(code, f"attention_bwd[B={B},N={N},H={H}]")
     return dqkv
 
