@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_generic_kernel(const __bf16* 
 //   dbias[n] += sum_{b,p} bf16(g[b, extra+p, n])
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, float* __restrict__ dpos,
                                                         float* __restrict__ dextra, __bf16* __restrict__ dyp,
-                                                        float* __restrict__ dbias, int B, int seq, int extra, int D, int bchunk) {
+                                                        float* __restrict__ dbias_rows, int B, int seq, int extra, int D, int bchunk) {
   const int t = blockIdx.x;  // token position
   const int b_lo = blockIdx.y * bchunk, b_hi = min(B, b_lo + bchunk);
   const int np = seq - extra;
@@ -172,9 +172,20 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     if (t < extra) atomicAdd(dextra + (size_t)t * D + c, s);   // outputs are zeroed by the caller
     else {
       atomicAdd(dpos + (size_t)(t - extra) * D + c, s);
-      atomicAdd(dbias + c, sb);
+      // per-position partial of the conv-bias gradient: few adders per address (B/bchunk); the
+      // positions are summed by embed_bias_reduce_kernel (a single hot [D] vector would serialise
+      // seq * B/bchunk workgroups on the same 768 addresses)
+      atomicAdd(dbias_rows + (size_t)(t - extra) * D + c, sb);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void embed_bias_reduce_kernel(const float* __restrict__ rows, float* __restrict__ dbias, int np, int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float s = 0.f;
+  for (int r = 0; r < np; ++r) s += rows[(size_t)r * D + c];
+  dbias[c] += s;
 }
 
 // idx[m] = argmin_k || x[m,:] - e[k,:] ||^2 (first minimum), fp32; the nearest-code search of the
@@ -271,11 +282,13 @@ extern "C" int vitamd_colsum_bf16(const void* x_bf16, float* out, int M, int N, 
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
-extern "C" int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16, float* dbias, int B, int seq,
-                                int extra, int D, void* stream) {
+extern "C" int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16, float* dbias, float* dbias_rows, int B,
+                                int seq, int extra, int D, void* stream) {
   if (B <= 0 || seq <= 0 || extra < 0 || extra > seq || D <= 0) return VITAMD_ERR_SHAPE;
-  if (!g || (seq > extra && (!dpos || !dyp_bf16 || !dbias)) || (extra > 0 && !dextra)) return VITAMD_ERR_ARG;
+  if (!g || (seq > extra && (!dpos || !dyp_bf16 || !dbias || !dbias_rows)) || (extra > 0 && !dextra)) return VITAMD_ERR_ARG;
   const int bchunk = 32;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(seq, (B + bchunk - 1) / bchunk), dim3(256), 0, (hipStream_t)stream, g, dpos, dextra, (__bf16*)dyp_bf16, dbias, B, seq, extra, D, bchunk);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(seq, (B + bchunk - 1) / bchunk), dim3(256), 0, (hipStream_t)stream, g, dpos, dextra, (__bf16*)dyp_bf16, dbias_rows, B, seq, extra, D, bchunk);
+  if (seq > extra)
+    hipLaunchKernelGGL(embed_bias_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dbias_rows, dbias, seq - extra, D);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

@@ -33,7 +33,7 @@ SIGNATURES = {
     "vitamd_cast_transpose_batched": [_P, _I, _I, _P],
     "vitamd_im2col_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "vitamd_colsum_bf16": [_P, _P, _I, _I, _I, _P],
-    "vitamd_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vitamd_embed_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vitamd_vq_nearest": [_P, _P, _P, _I, _I, _I, _P],
     "vitamd_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
 }

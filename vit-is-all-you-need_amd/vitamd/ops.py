@@ -195,7 +195,8 @@ def embed_bwd(g, B, seq, extra, D):
     dextra = torch.zeros((extra, D), dtype=F32, device=dev)
     dyp = torch.empty((B * n_p, D), dtype=BF16, device=dev)
     dbias = torch.zeros((D,), dtype=F32, device=dev)
-    _lib.check(_L().vitamd_embed_bwd(_p(g), _p(dpos), _p(dextra) if extra > 0 else None, _p(dyp), _p(dbias), B, seq, extra, D,
+    rows = torch.zeros((max(n_p, 1), D), dtype=F32, device=dev)
+    _lib.check(_L().vitamd_embed_bwd(_p(g), _p(dpos), _p(dextra) if extra > 0 else None, _p(dyp), _p(dbias), _p(rows), B, seq, extra, D,
                                      _stream()), "embed_bwd")
     return dpos, dextra, dyp, dbias
 
