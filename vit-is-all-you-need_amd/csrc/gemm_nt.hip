@@ -8,6 +8,15 @@
 // 16-B chunk index XOR-ed with (row & 7) (applied on the global SOURCE address, LDS image stays
 // lane-linear) so the ds_read_b128 fragment reads are bank-conflict-free (tools/lds_banks.py).
 // mfma_f32_16x16x32_bf16 with A/B swapped (D[n][m]) so each lane owns 4 consecutive output columns.
+//
+// Kernels in this file (DESIGN.md section 4 has the measurements):
+//   gemm_nt_pipe_kernel     256x256x64, 8 waves, grouped DMA/ds_read/MFMA issue        <- production (auto, tile=2)
+//   gemm_nt_kernel          plain double-buffered; 128x128 instance serves small problems (auto) / tile=256
+//   gemm_nt_persist_kernel  pipe + persistent tile loop with cross-tile prefetch         (tile=6, neutral)
+//   gemm_nt_ring_kernel     256x128, BK=32, 3-stage ring, 2 workgroups per CU            (tile=1, slower)
+//   gemm_nt_deep_kernel     256x256, BK=32, 3..5-stage ring                              (tile=3..5, neutral)
+// Epilogues: gemm_epilogue_rows (LDS-transposed, row-major 16-B accesses; production),
+//            epilogue_rows_halves (same in 64-KiB of LDS; persistent kernel), gemm_epilogue (direct; small tiles).
 #include "common.h"
 #include "vitamd_internal.h"
 
