@@ -44,6 +44,11 @@ int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, con
                         float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
                         int tile, void* stream);
 
+/* fc2 with dropout: out f32 = resid + dropout_p(bf16(A.B^T + bias)), mask = hash(seed, row*N+col).
+ * replaces transformer.py:39-40,44 (Linear + nn.Dropout(p) + residual add) in training mode. */
+int vitamd_linear_dropout_resid_bf16(const void* A, const void* B, float* out, const float* bias, const float* resid,
+                                     int M, int N, int K, float dropout_p, unsigned long long seed, void* stream);
+
 /* Weight gradient: out[P,Q] (fp32) += sum_r L[r,p] * Rm[r,q]   (dW = dY^T X).  Accumulates with
  * fp32 atomics, so `out` must hold the running gradient (zeros for a fresh one).
  * replaces the autograd backward of transformer.py:21,37,39 and train_vit.py:34.
@@ -66,21 +71,31 @@ int vitamd_layernorm_fwd(const float* x_in, const void* addend_bf16, float* x_ou
 /* backward: g_out = (g_res ? g_res : 0) + LN'(dy_bf16); optional bf16 copy of g_out and its column sums. */
 int vitamd_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
                          const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D, void* stream);
+/* same; the bf16 copy additionally carries the dropout mask (p, seed; element index row*D+col) of the
+ * Linear output whose gradient it is (backward of the nn.Dropout of transformer.py:40). */
+int vitamd_layernorm_bwd_dropout(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                 const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D,
+                                 float dropout_p, unsigned long long seed, void* stream);
 
 /* ---- Attention on the packed fused-QKV layout ------------------------------------------------
  * qkv bf16 [B,N,3,H,64] (output-channel order (qkv, head, dh) of transformer.py:27), o bf16 [B,N,H*64],
  * lse2 fp32 [B,H,N].  head_dim must be 64, N <= 512.  causal != 0 applies the strictly-upper -inf
- * mask of transformer.py:22-25.   replaces transformer.py:27-29 (rearrange + SDPA + rearrange). */
+ * mask of transformer.py:22-25.   replaces transformer.py:27-29 (rearrange + SDPA + rearrange).
+ * dropout_p in [0,1): dropout on the softmax probabilities (SDPA's dropout_p); the mask is a stateless
+ * hash of (seed, batch, head, query, key), so the backward call regenerates it from the same seed. */
 int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal,
-                         void* stream);
+                         float dropout_p, unsigned long long seed, void* stream);
 /* dqkv bf16 [B,N,3,H,64]; delta fp32 [B,H,N] is scratch written by the call; dbias (may be NULL) fp32
  * [3*H*64]: the column sums of dqkv (= gradient of the QKV bias, transformer.py:21) are ADDED to it. */
 int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, const void* d_o, void* dqkv,
-                         float* delta, float* dbias, int B, int N, int H, int head_dim, int causal, void* stream);
+                         float* delta, float* dbias, int B, int N, int H, int head_dim, int causal, float dropout_p,
+                         unsigned long long seed, void* stream);
 
 /* ---- helpers around the GEMMs ---------------------------------------------------------------- */
 /* fp32 -> bf16 (autocast's per-step weight / activation cast, train_vit.py:100). */
 int vitamd_cast_f32_bf16(const float* in, void* out_bf16, long n, void* stream);
+/* bf16(x) * dropout mask (p, seed; element index) — the top layer's fc2 output gradient under dropout. */
+int vitamd_cast_f32_bf16_dropout(const float* in, void* out_bf16, long n, float dropout_p, unsigned long long seed, void* stream);
 /* W fp32 [N,K] -> bf16 [N,K] (wb, may be NULL) and transposed bf16 [K,N] (wbt, may be NULL). */
 int vitamd_cast_transpose_weight(const float* w, void* wb, void* wbt, int N, int K, void* stream);
 /* The same for n weights in ONE launch.  desc_dev: device array of n records

@@ -74,8 +74,10 @@ def test_no_cpu_fallback():
     with pytest.raises(lib.VitamdError):
         m(torch.randn(2, 3, 32, 32))
     import transformer as T
-    with pytest.raises(NotImplementedError):
-        T.Transformer(T.S(block_size=5, dropout=0.1))(torch.randn(1, 5, 512))
+    with pytest.raises(lib.VitamdError):
+        T.Transformer(T.S(block_size=5, dropout=0.1))(torch.randn(1, 5, 512))   # dropout is supported, host tensors are not
+    with pytest.raises(ValueError):
+        T.Transformer(T.S(block_size=5, dropout=1.5))(torch.randn(1, 5, 512))
 
 
 def test_lr_scheduler_reproduces_reference_trace():

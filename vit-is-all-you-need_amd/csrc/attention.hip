@@ -145,9 +145,20 @@ struct AttnArgs {
   int causal;
   float scale_log2e;   // (1/sqrt(dh)) * log2(e)
   float scale;         // 1/sqrt(dh)
+  // dropout on the softmax probabilities (reference transformer.py:28 dropout_p); thresh = p * 2^32, 0 = off
+  unsigned drop_thresh;
+  float drop_scale;
+  unsigned seed_lo, seed_hi;
 };
 
+// keep-scale of probability (b, head, query, key): 1/(1-p) or 0
+__device__ __forceinline__ float attn_keep(const AttnArgs& a, int bh, int query, int key) {
+  const unsigned long long idx = ((unsigned long long)bh * a.N + query) * a.N + key;
+  return dropout_keep(idx, a.seed_lo, a.seed_hi, a.drop_thresh, a.drop_scale);
+}
+
 // ------------------------------------------------------------------------------------------ forward
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -198,6 +209,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
       for (int r = 0; r < 16; ++r) {
         s[r] = fast_exp2(__builtin_fmaf(s[r], c, -mnew));
         psum += s[r];
+        if constexpr (DROP) s[r] *= attn_keep(a, blockIdx.x, min(qrow, N - 1), min(32 * T + acc_row(r, lane), N - 1));
       }
       l = l * alpha + psum;
 #pragma unroll
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 // The whole score row of a query fits in registers (NKT tiles x 16 fp32), so there is no online
 // rescaling: S for every key tile, one row maximum, exp2, then P.V.  Per element the VALU work is
 // fma + v_exp + add + cvt (the kernel is VALU-bound at dh = 64, not MFMA-bound).
-template <int NKT>
+template <int NKT, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -279,8 +291,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
       if (T < t_end) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pexp = fast_exp2(__builtin_fmaf(s[T][r], c, -mc));
+          float pexp = fast_exp2(__builtin_fmaf(s[T][r], c, -mc));
           l += pexp;
+          if constexpr (DROP) pexp *= attn_keep(a, blockIdx.x, min(qrow, N - 1), min(32 * T + acc_row(r, lane), N - 1));
           s[T][r] = pexp;
         }
 #pragma unroll
@@ -300,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
 }
 
 // ------------------------------------------------------------------------------------------ backward, dQ
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -354,7 +368,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
-        s[r] = pexp * (dp[r] - delta);  // dS^T (the 1/sqrt(dh) factor is applied once at the end)
+        float dpr = dp[r];
+        if constexpr (DROP) dpr *= attn_keep(a, blockIdx.x, min(qrow, N - 1), min(32 * T + acc_row(r, lane), N - 1));
+        s[r] = pexp * (dpr - delta);  // dS^T (the 1/sqrt(dh) factor is applied once at the end)
       }
       if (32 * T + 32 > N || (a.causal && T == qb)) {   // boundary tiles: zero the masked keys
 #pragma unroll
@@ -377,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ backward, dK and dV
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -433,8 +450,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * u + i;
           const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse4[i]));
-          pmat[r] = pexp;
-          s[r] = pexp * (dp[r] - del4[i]);
+          float keep = 1.0f;
+          if constexpr (DROP) keep = attn_keep(a, blockIdx.x, min(qr + i, N - 1), min(krow, N - 1));
+          pmat[r] = pexp * keep;
+          s[r] = pexp * (dp[r] * keep - del4[i]);
         }
         if (32 * T + 32 > N || k0 + 32 > N || (a.causal && T == kb)) {   // boundary tiles only (wave-uniform)
 #pragma unroll
@@ -477,41 +496,74 @@ int set_lds(K kern, int bytes) {
 
 }  // namespace
 
-extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal, void* stream) {
+static bool attn_dropout(AttnArgs& a, float p, unsigned long long seed) {
+  if (!(p >= 0.f) || p >= 1.f) return false;
+  a.drop_thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  if (p > 0.f && a.drop_thresh == 0u) a.drop_thresh = 1u;
+  a.drop_scale = 1.0f / (1.0f - p);
+  a.seed_lo = (unsigned)seed;
+  a.seed_hi = (unsigned)(seed >> 32);
+  return true;
+}
+
+template <int K, bool DROP>
+static int launch_fwd_small(const AttnArgs& a, int lds, hipStream_t stream) {
+  if (int e = set_lds(attn_fwd_small_kernel<K, DROP>, lds)) return e;
+  hipLaunchKernelGGL((attn_fwd_small_kernel<K, DROP>), dim3(a.B * a.H), dim3(256), lds, stream, a);
+  return VITAMD_OK;
+}
+
+extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal,
+                                    float dropout_p, unsigned long long seed, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
-  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f};
+  AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f,
+             0u, 1.0f, 0u, 0u};
   if (int e = check(a)) return e;
-  if (!qkv || !o || !lse2) return VITAMD_ERR_ARG;
+  if (!qkv || !o || !lse2 || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
+  const bool drop = a.drop_thresh != 0u;
   const int nkt = (N + 31) / 32, npad = nkt * 32;
   if (nkt <= 8) {
     const int lds = 2 * npad * 128 + 4 * 4096;
-#define FWD_SMALL(K)                                                                                          \
-  case K:                                                                                                     \
-    if (int e = set_lds(attn_fwd_small_kernel<K>, lds)) return e;                                             \
-    hipLaunchKernelGGL(attn_fwd_small_kernel<K>, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);         \
-    break;
+    int e = VITAMD_OK;
+#define FWD_SMALL(K) case K: e = drop ? launch_fwd_small<K, true>(a, lds, stream) : launch_fwd_small<K, false>(a, lds, stream); break;
     switch (nkt) { FWD_SMALL(1) FWD_SMALL(2) FWD_SMALL(3) FWD_SMALL(4) FWD_SMALL(5) FWD_SMALL(6) FWD_SMALL(7) FWD_SMALL(8) }
 #undef FWD_SMALL
+    if (e) return e;
   } else {
     const int lds = 2 * npad * 128;
-    if (int e = set_lds(attn_fwd_kernel, lds)) return e;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+    if (drop) {
+      if (int e = set_lds(attn_fwd_kernel<true>, lds)) return e;
+      hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(256), lds, stream, a);
+    } else {
+      if (int e = set_lds(attn_fwd_kernel<false>, lds)) return e;
+      hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(256), lds, stream, a);
+    }
   }
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
 extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, const void* d_o, void* dqkv, float* delta,
-                                    float* dbias, int B, int N, int H, int head_dim, int causal, void* stream) {
+                                    float* dbias, int B, int N, int H, int head_dim, int causal, float dropout_p,
+                                    unsigned long long seed, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
   AttnArgs a{(const __bf16*)qkv, (__bf16*)o, (float*)lse2, (const __bf16*)d_o, (__bf16*)dqkv, delta, dbias, B, N, H, causal,
-             0.125f * 1.4426950408889634f, 0.125f};
+             0.125f * 1.4426950408889634f, 0.125f, 0u, 1.0f, 0u, 0u};
   if (int e = check(a)) return e;
-  if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta) return VITAMD_ERR_ARG;
+  if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
   const int npad = (N + 31) / 32 * 32;
   const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
-  if (int e = set_lds(attn_bwd_dq_kernel, lds1)) return e;
-  if (int e = set_lds(attn_bwd_dkv_kernel, lds2)) return e;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H), dim3(256), lds1, (hipStream_t)stream, a);   // also writes delta
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(256), lds2, (hipStream_t)stream, a);
+  if (a.drop_thresh) {
+    if (int e = set_lds(attn_bwd_dq_kernel<true>, lds1)) return e;
+    if (int e = set_lds(attn_bwd_dkv_kernel<true>, lds2)) return e;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(B * H), dim3(256), lds1, stream, a);   // also writes delta
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(B * H), dim3(256), lds2, stream, a);
+  } else {
+    if (int e = set_lds(attn_bwd_dq_kernel<false>, lds1)) return e;
+    if (int e = set_lds(attn_bwd_dkv_kernel<false>, lds2)) return e;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(B * H), dim3(256), lds1, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(B * H), dim3(256), lds2, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

@@ -3,7 +3,7 @@
 #include "vitamd_internal.h"
 #include "../../include/vitamd.h"
 
-extern "C" int vitamd_abi_version(void) { return 2; }
+extern "C" int vitamd_abi_version(void) { return 3; }
 
 int g_vitamd_debug = 0;
 // timing-only ablation knob for tools/ablate_*.py (bit 0: skip GELU math, bit 1: skip the second store,
@@ -13,7 +13,7 @@ extern "C" int vitamd_set_debug(int bits) { g_vitamd_debug = bits; return 0; }
 extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
                                    float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
                                    int tile, void* stream) {
-  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug};
+  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug, 0u, 1.0f, 0u, 0u, 0};
   if (!(tile >= 0 && tile <= 6) && tile != 128 && tile != 256 && (tile < 21 || tile > 24)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }
@@ -28,4 +28,21 @@ extern "C" int vitamd_gemm_tn_bf16_ws(const void* L, const void* Rm, float* out,
                                       int splits, float* ws, long ws_bytes, int accumulate, void* stream) {
   GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits, ws, (size_t)(ws_bytes < 0 ? 0 : ws_bytes), accumulate};
   return vitamd_gemm_tn_impl(a, (hipStream_t)stream);
+}
+
+static bool dropout_params(float p, unsigned& thresh, float& scale) {
+  if (!(p >= 0.0f) || p >= 1.0f) return false;
+  thresh = p > 0.0f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  if (p > 0.0f && thresh == 0u) thresh = 1u;
+  scale = 1.0f / (1.0f - p);
+  return true;
+}
+
+// fc2 with dropout: out f32 = resid + dropout_p(bf16(A.B^T + bias)) — reference transformer.py:39-40,44
+extern "C" int vitamd_linear_dropout_resid_bf16(const void* A, const void* B, float* out, const float* bias, const float* resid,
+                                                int M, int N, int K, float dropout_p, unsigned long long seed, void* stream) {
+  GemmNtArgs p{A, B, out, nullptr, bias, resid, nullptr, M, N, K, N, EPI_RESID_F32, 0, 0, 0, 0, g_vitamd_debug, 0u, 1.0f,
+               (unsigned)seed, (unsigned)(seed >> 32), 0};
+  if (!dropout_params(dropout_p, p.drop_thresh, p.drop_scale)) return VITAMD_ERR_ARG;
+  return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }

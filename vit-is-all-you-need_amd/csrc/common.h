@@ -64,6 +64,19 @@ __device__ __forceinline__ float gelu_grad(float x) {
   return cdf + x * pdf;
 }
 
+// Counter-based dropout: element `idx` of a tensor is kept with probability 1-p, decided by a
+// stateless 64->32-bit integer hash of (idx, seed), so forward and backward regenerate the same mask
+// from (seed, index) and nothing is stored.  thresh = p * 2^32; returns 1/(1-p) (kept) or 0 (dropped).
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float dropout_keep(unsigned long long idx, unsigned seed_lo, unsigned seed_hi, unsigned thresh, float scale) {
+  unsigned h = mix32((unsigned)idx ^ seed_lo);
+  h = mix32(h ^ (unsigned)(idx >> 32) ^ seed_hi);
+  return h >= thresh ? scale : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

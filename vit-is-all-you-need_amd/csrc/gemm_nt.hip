@@ -78,7 +78,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
         const f32x4 res = (p.dbg & 4) ? v : *(const f32x4*)((const float*)p.aux + (size_t)m * ldo + n);
         f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = res[r] + round_bf16(v[r]);
+        for (int r = 0; r < 4; ++r) {
+          float y = round_bf16(v[r]);
+          if (p.drop_thresh) y = round_bf16(y * dropout_keep((unsigned long long)(p.row0 + m) * p.N + n + r, p.drop_seed_lo, p.drop_seed_hi, p.drop_thresh, p.drop_scale));
+          o[r] = res[r] + y;
+        }
         *(f32x4*)((float*)p.out + (size_t)m * ldo + n) = o;
       } else if constexpr (EPI == EPI_DGELU) {
         const u32x2 pz = *(const u32x2*)((const __bf16*)p.aux + (size_t)m * ldo + n);
@@ -242,8 +246,16 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
       }
     } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) {
       const f32x4 r0 = auxf[2 * it], r1 = auxf[2 * it + 1];
-      f32x4 o0 = {r0[0] + bf16lo(v[0]), r0[1] + bf16hi(v[0]), r0[2] + bf16lo(v[1]), r0[3] + bf16hi(v[1])};
-      f32x4 o1 = {r1[0] + bf16lo(v[2]), r1[1] + bf16hi(v[2]), r1[2] + bf16lo(v[3]), r1[3] + bf16hi(v[3])};
+      float y8[8] = {bf16lo(v[0]), bf16hi(v[0]), bf16lo(v[1]), bf16hi(v[1]), bf16lo(v[2]), bf16hi(v[2]), bf16lo(v[3]), bf16hi(v[3])};
+      if constexpr (EPI == EPI_RESID_F32) {
+        if (p.drop_thresh) {
+          const unsigned long long base = (unsigned long long)(p.row0 + m) * p.N + n;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) y8[c] = round_bf16(y8[c] * dropout_keep(base + c, p.drop_seed_lo, p.drop_seed_hi, p.drop_thresh, p.drop_scale));
+        }
+      }
+      f32x4 o0 = {r0[0] + y8[0], r0[1] + y8[1], r0[2] + y8[2], r0[3] + y8[3]};
+      f32x4 o1 = {r1[0] + y8[4], r1[1] + y8[5], r1[2] + y8[6], r1[3] + y8[7]};
       size_t orow = (size_t)m;
       if constexpr (EPI == EPI_PATCH_F32) {
         const int b = m / p.n_patches, pidx = m - b * p.n_patches;
@@ -821,8 +833,16 @@ __device__ __forceinline__ void epilogue_rows_halves(const GemmNtArgs& p, f32x4 
         }
       } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) {
         const f32x4 r0 = auxf[2 * it], r1 = auxf[2 * it + 1];
-        f32x4 o0 = {r0[0] + bf16lo(v[0]), r0[1] + bf16hi(v[0]), r0[2] + bf16lo(v[1]), r0[3] + bf16hi(v[1])};
-        f32x4 o1 = {r1[0] + bf16lo(v[2]), r1[1] + bf16hi(v[2]), r1[2] + bf16lo(v[3]), r1[3] + bf16hi(v[3])};
+        float y8[8] = {bf16lo(v[0]), bf16hi(v[0]), bf16lo(v[1]), bf16hi(v[1]), bf16lo(v[2]), bf16hi(v[2]), bf16lo(v[3]), bf16hi(v[3])};
+        if constexpr (EPI == EPI_RESID_F32) {
+          if (p.drop_thresh) {
+            const unsigned long long base = (unsigned long long)(p.row0 + m) * p.N + n;
+  #pragma unroll
+            for (int c = 0; c < 8; ++c) y8[c] = round_bf16(y8[c] * dropout_keep(base + c, p.drop_seed_lo, p.drop_seed_hi, p.drop_thresh, p.drop_scale));
+          }
+        }
+        f32x4 o0 = {r0[0] + y8[0], r0[1] + y8[1], r0[2] + y8[2], r0[3] + y8[3]};
+        f32x4 o1 = {r1[0] + y8[4], r1[1] + y8[5], r1[2] + y8[6], r1[3] + y8[7]};
         size_t orow = (size_t)m;
         if constexpr (EPI == EPI_PATCH_F32) {
           const int b = m / p.n_patches, pidx = m - b * p.n_patches;
@@ -1094,6 +1114,7 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
       if (p.out2) b.out2 = (char*)p.out2 + (size_t)rows_a * p.ldo * 2;
       if (p.aux) b.aux = (const char*)p.aux + (size_t)rows_a * p.ldo * (p.epi == EPI_RESID_F32 ? 4 : 2);
       b.tile = 128;
+      b.row0 = p.row0 + rows_a;
       if (int e = dispatch_epi(a, stream)) return e;
       return dispatch_epi(b, stream);
     }

@@ -80,7 +80,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ g_res, float* __restrict__ g_out,
-                                                     __bf16* __restrict__ g_bf16, float* __restrict__ colsum, int M) {
+                                                     __bf16* __restrict__ g_bf16, float* __restrict__ colsum, int M,
+                                                     unsigned dthresh, float dscale, unsigned dseed_lo, unsigned dseed_hi) {
   constexpr int D = NV * 256;
   __shared__ float red[ROWS_PER_BLOCK][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,6 +115,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
       *(f32x4*)(g_out + base + j * 256 + lane * 4) = g;
       if (g_bf16) {
         u32x2 o = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
+        if (dthresh) {   // the bf16 copy is the gradient of a dropped-out Linear output: same mask as the forward
+          const unsigned long long e0 = (unsigned long long)base + j * 256 + lane * 4;
+          o[0] = pack_bf16x2(bf16lo(o[0]) * dropout_keep(e0, dseed_lo, dseed_hi, dthresh, dscale),
+                             bf16hi(o[0]) * dropout_keep(e0 + 1, dseed_lo, dseed_hi, dthresh, dscale));
+          o[1] = pack_bf16x2(bf16lo(o[1]) * dropout_keep(e0 + 2, dseed_lo, dseed_hi, dthresh, dscale),
+                             bf16hi(o[1]) * dropout_keep(e0 + 3, dseed_lo, dseed_hi, dthresh, dscale));
+        }
         *(u32x2*)(g_bf16 + base + j * 256 + lane * 4) = o;
         if (colsum) {
           cs[j][0] += bf16lo(o[0]); cs[j][1] += bf16hi(o[0]); cs[j][2] += bf16lo(o[1]); cs[j][3] += bf16hi(o[1]);
@@ -137,7 +145,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 __global__ __launch_bounds__(256) void ln_bwd_generic(const __bf16* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ g_res, float* __restrict__ g_out,
-                                                      __bf16* __restrict__ g_bf16, float* __restrict__ colsum, int M, int D) {
+                                                      __bf16* __restrict__ g_bf16, float* __restrict__ colsum, int M, int D,
+                                                      unsigned dthresh, float dscale, unsigned dseed_lo, unsigned dseed_hi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * ROWS_PER_BLOCK) {
     const size_t base = (size_t)row * D;
@@ -155,7 +164,8 @@ __global__ __launch_bounds__(256) void ln_bwd_generic(const __bf16* __restrict__
       if (g_res) g += g_res[base + c];
       g_out[base + c] = g;
       if (g_bf16) {
-        const __bf16 gb = f2bf(g);
+        __bf16 gb = f2bf(g);
+        if (dthresh) gb = f2bf(bf2f(gb) * dropout_keep((unsigned long long)base + c, dseed_lo, dseed_hi, dthresh, dscale));
         g_bf16[base + c] = gb;
         if (colsum) atomicAdd(colsum + c, bf2f(gb));
       }
@@ -191,21 +201,39 @@ extern "C" int vitamd_layernorm_fwd(const float* x_in, const void* addend_bf16, 
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
-extern "C" int vitamd_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
-                                    const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D,
-                                    void* stream_) {
+static int ln_bwd_launch(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* g_res, float* g_out,
+                         void* g_bf16, float* colsum, int M, int D, float dropout_p, unsigned long long seed, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (M <= 0 || D <= 0 || D % 4) return VITAMD_ERR_SHAPE;
   if (!dy_bf16 || !x || !mean || !rstd || !g_out) return VITAMD_ERR_ARG;
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return VITAMD_ERR_ARG;
+  unsigned dthresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  if (dropout_p > 0.f && dthresh == 0u) dthresh = 1u;
+  const float dscale = 1.0f / (1.0f - dropout_p);
+  const unsigned slo = (unsigned)seed, shi = (unsigned)(seed >> 32);
   const __bf16* dy = (const __bf16*)dy_bf16;
   __bf16* gb = (__bf16*)g_bf16;
   const int grid = grid_for(M);
-#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(grid), dim3(256), 0, stream, dy, x, mean, rstd, g_res, g_out, gb, colsum, M)
+#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(grid), dim3(256), 0, stream, dy, x, mean, rstd, g_res, g_out, gb, colsum, M, dthresh, dscale, slo, shi)
   if (D == 256) { LN_BWD(1); }
   else if (D == 512) { LN_BWD(2); }
   else if (D == 768) { LN_BWD(3); }
   else if (D == 1024) { LN_BWD(4); }
-  else hipLaunchKernelGGL(ln_bwd_generic, dim3(grid), dim3(256), 0, stream, dy, x, mean, rstd, g_res, g_out, gb, colsum, M, D);
+  else hipLaunchKernelGGL(ln_bwd_generic, dim3(grid), dim3(256), 0, stream, dy, x, mean, rstd, g_res, g_out, gb, colsum, M, D, dthresh, dscale, slo, shi);
 #undef LN_BWD
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+extern "C" int vitamd_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                    const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D,
+                                    void* stream) {
+  return ln_bwd_launch(dy_bf16, x, mean, rstd, g_res, g_out, g_bf16, colsum, M, D, 0.f, 0ull, stream);
+}
+
+// same; the bf16 copy (and its column sums) additionally gets the dropout mask (p, seed) of the
+// Linear output whose gradient it is (index = row * D + column, as in vitamd_linear_dropout_resid_bf16)
+extern "C" int vitamd_layernorm_bwd_dropout(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                            const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D,
+                                            float dropout_p, unsigned long long seed, void* stream) {
+  return ln_bwd_launch(dy_bf16, x, mean, rstd, g_res, g_out, g_bf16, colsum, M, D, dropout_p, seed, stream);
 }

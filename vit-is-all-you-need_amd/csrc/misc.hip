@@ -15,6 +15,14 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
   if (blockIdx.x == 0) for (size_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) out[i] = f2bf(in[i]);
 }
 
+// bf16(x) with a dropout mask on the rounded value: the top layer's fc2 output gradient when dropout is on
+__global__ __launch_bounds__(256) void cast_dropout_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n,
+                                                           unsigned thresh, float scale, unsigned slo, unsigned shi) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = f2bf(round_bf16(in[i]) * dropout_keep(i, slo, shi, thresh, scale));
+}
+
 // W fp32 [N,K] -> Wb bf16 [N,K] (optional) and WbT bf16 [K,N] (optional); 64x64 tiles through LDS
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, __bf16* __restrict__ wb,
                                                              __bf16* __restrict__ wbt, int N, int K) {
@@ -235,6 +243,17 @@ extern "C" int vitamd_cast_f32_bf16(const float* in, void* out_bf16, long n, voi
   const size_t n8 = (size_t)n / 8;
   int grid = (int)((n8 + 255) / 256); grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (__bf16*)out_bf16, n8, (size_t)n);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+extern "C" int vitamd_cast_f32_bf16_dropout(const float* in, void* out_bf16, long n, float dropout_p, unsigned long long seed, void* stream) {
+  if (n <= 0) return n == 0 ? VITAMD_OK : VITAMD_ERR_SHAPE;
+  if (!in || !out_bf16 || !(dropout_p >= 0.f) || dropout_p >= 1.f) return VITAMD_ERR_ARG;
+  unsigned thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  if (dropout_p > 0.f && thresh == 0u) thresh = 1u;
+  int grid = (int)(((size_t)n + 255) / 256); grid = grid > 8192 ? 8192 : grid;
+  hipLaunchKernelGGL(cast_dropout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (__bf16*)out_bf16, (size_t)n, thresh,
+                     1.0f / (1.0f - dropout_p), (unsigned)seed, (unsigned)(seed >> 32));
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 

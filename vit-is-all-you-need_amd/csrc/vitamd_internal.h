@@ -24,6 +24,11 @@ struct GemmNtArgs {
   int n_patches, seq, extra;  // EPI_PATCH_F32 row remap
   int tile;                   // 0 = auto, 128, 256
   int dbg;                    // timing-only ablation bits (vitamd_set_debug); 0 in production
+  // EPI_RESID_F32 only: dropout on the Linear output before the residual add (reference nn.Dropout, transformer.py:40)
+  unsigned drop_thresh;       // p * 2^32, 0 = off
+  float drop_scale;           // 1 / (1 - p)
+  unsigned drop_seed_lo, drop_seed_hi;
+  int row0;                   // global row of this launch's row 0 (tail split): dropout indices stay global
 };
 
 struct GemmTnArgs {

@@ -41,10 +41,8 @@ def _adopt(module: nn.Module, config: TransformerConfig):
 
 
 def _check_dropout(p: float):
-    if p != 0.0:
-        raise NotImplementedError(
-            "dropout > 0 is not implemented on the HIP path (every measured configuration uses 0.0; "
-            "the reference applies SDPA dropout even in eval(), transformer.py:28)")
+    if not (0.0 <= p < 1.0):
+        raise ValueError(f"dropout must be in [0, 1), got {p}")
 
 
 class Attention(nn.Module):
@@ -60,7 +58,9 @@ class Attention(nn.Module):
 
     def forward(self, x):
         _check_dropout(self.dropout)
-        return AttentionFn.apply(x, self.qkv.weight, self.qkv.bias, self.n_heads, bool(self.causal))
+        # like the reference, the SDPA dropout is applied in eval() as well (transformer.py:28 passes
+        # dropout_p=self.dropout unconditionally)
+        return AttentionFn.apply(x, self.qkv.weight, self.qkv.bias, self.n_heads, bool(self.causal), float(self.dropout))
 
 
 class TransformerLayer(nn.Module):
@@ -83,7 +83,8 @@ class TransformerLayer(nn.Module):
 
     def forward(self, x):
         _check_dropout(self.dropout)
-        return TransformerLayerFn.apply(x, *self._params(), self.n_heads, bool(self.causal))
+        p_mlp = float(self.dropout) if self.training else 0.0          # nn.Dropout in the MLP follows train/eval
+        return TransformerLayerFn.apply(x, *self._params(), self.n_heads, bool(self.causal), float(self.dropout), p_mlp)
 
 
 class Transformer(nn.Module):
@@ -97,7 +98,8 @@ class Transformer(nn.Module):
     def forward(self, x):
         _check_dropout(self.dropout)
         params = [p for layer in self.layers for p in layer._params()]
-        return TransformerStackFn.apply(x, self.n_heads, bool(self.causal), *params)
+        p_mlp = float(self.dropout) if self.training else 0.0
+        return TransformerStackFn.apply(x, self.n_heads, bool(self.causal), float(self.dropout), p_mlp, *params)
 
 
 def S(**kwargs): return TransformerConfig(n_layers=6, n_heads=8, n_embd=512, **kwargs)

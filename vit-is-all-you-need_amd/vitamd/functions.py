@@ -106,19 +106,30 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------------
 # one pre-LN transformer layer (reference transformer.py:42-45)
 # ------------------------------------------------------------------------------------------------
-def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad):
-    """x0 fp32 [M,D] -> x2 fp32 [M,D] and the tensors backward needs."""
+def new_seed():
+    """64-bit dropout seed from torch's CPU generator (so torch.manual_seed makes runs repeatable)"""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad, p_attn=0.0, p_mlp=0.0):
+    """x0 fp32 [M,D] -> x2 fp32 [M,D], the tensors backward needs, and the dropout record
+    (p_attn, seed_attn, p_mlp, seed_mlp).  p_attn: SDPA dropout_p (transformer.py:28); p_mlp: the
+    nn.Dropout after fc2 (transformer.py:40)."""
+    drop = (p_attn, new_seed() if p_attn > 0 else 0, p_mlp, new_seed() if p_mlp > 0 else 0)
     wqkv_b, _ = WEIGHTS.get(wqkv, need_grad)
     w1_b, _ = WEIGHTS.get(w1, need_grad)
     w2_b, _ = WEIGHTS.get(w2, need_grad)
     _, a, mean1, rstd1 = ops.layernorm_fwd(x0)                                   # LN1            transformer.py:43
     qkv = ops.gemm_nt(a, wqkv_b, ops.EPI_BIAS_BF16, bias=bqkv)                   # fused QKV      transformer.py:27
-    o, lse = ops.attention_fwd(qkv, B, N, H, causal)                             # SDPA           transformer.py:28-29
+    o, lse = ops.attention_fwd(qkv, B, N, H, causal, dropout=drop[:2])           # SDPA           transformer.py:28-29
     x1, bln, mean2, rstd2 = ops.layernorm_fwd(x0, addend=o)                      # residual + LN2 transformer.py:43-44
     pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU, bias=b1)                       # fc1 + GELU     transformer.py:37-38
-    x2 = ops.gemm_nt(h, w2_b, ops.EPI_RESID_F32, bias=b2, aux=x1)                # fc2 + residual transformer.py:39,44
+    if p_mlp > 0:
+        x2 = ops.linear_dropout_resid(h, w2_b, b2, x1, drop[2:])                 # fc2 + dropout + residual
+    else:
+        x2 = ops.gemm_nt(h, w2_b, ops.EPI_RESID_F32, bias=b2, aux=x1)            # fc2 + residual transformer.py:39,44
     saved = (x0, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, bln, pre, h) if need_grad else None
-    return x2, saved
+    return x2, saved, drop
 
 
 class _Side:
@@ -175,12 +186,13 @@ def grad_arena(D, n_layers, device, params=None):
 
 
 def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, have_db2=False, emit_bf16=False,
-                   emit_colsum=None):
+                   emit_colsum=None, drop=(0.0, 0, 0.0, 0), emit_dropout=(0.0, 0)):
     """g2 fp32 [M,D] = dL/dx2.  Fills `grads` = (dWqkv, dbqkv, dW1, db1, dW2, db2) (zero-initialised
     fp32, accumulated into) and returns (g0, bf16(g0) or None).
     dy2: bf16(g2) if a previous kernel already produced it (then db2 is already in grads[5] when
     have_db2).  emit_bf16/emit_colsum: also produce bf16(g0) and add its column sums to emit_colsum
-    (the fc2 bias gradient of the layer below)."""
+    (the fc2 bias gradient of the layer below); emit_dropout = that layer's fc2 dropout (p, seed), whose
+    mask the emitted copy must carry.  drop = this layer's dropout record from layer_forward."""
     x0, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, bln, pre, h = saved
     dWqkv, dbqkv, dW1, db1, dW2, db2 = grads
     main = torch.cuda.current_stream()
@@ -203,7 +215,7 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
     _, w1_t = WEIGHTS.get(w1, True)
     _, w2_t = WEIGHTS.get(w2, True)
     if dy2 is None:
-        dy2 = ops.cast_bf16(g2)
+        dy2 = ops.cast_bf16_dropout(g2, drop[2:]) if drop[2] > 0 else ops.cast_bf16(g2)
     # ---- MLP
     def wgrad_fc2():
         ops.gemm_tn(dy2, h, dW2, accumulate=False)
@@ -215,10 +227,10 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True)
     # ---- attention
-    dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=dbqkv)    # also adds the QKV bias gradient
+    dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=dbqkv, dropout=drop[:2])   # also adds the QKV bias gradient
     on_side(lambda: ops.gemm_tn(dqkv, a, dWqkv, accumulate=False), dqkv, a, dWqkv)
     da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
-    g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum)
+    g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum, dropout=emit_dropout)
     return g0, g0b
 
 
@@ -232,14 +244,15 @@ def join_side(device):
 
 class TransformerLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wqkv, bqkv, w1, b1, w2, b2, n_heads, causal):
+    def forward(ctx, x, wqkv, bqkv, w1, b1, w2, b2, n_heads, causal, p_attn=0.0, p_mlp=0.0):
         B, N, D = x.shape
         need_grad = any(ctx.needs_input_grad)
-        x2, saved = layer_forward(_f32c(x).view(B * N, D), wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads,
-                                  causal, need_grad)
+        x2, saved, drop = layer_forward(_f32c(x).view(B * N, D), wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads,
+                                        causal, need_grad, p_attn, p_mlp)
         if need_grad:
             ctx.save_for_backward(*saved)
             ctx.weights = (wqkv, w1, w2)
+        ctx.drop = drop
         ctx.meta = (B, N, D, n_heads, causal, x.dtype)
         return x2.view(B, N, D).to(x.dtype)
 
@@ -248,9 +261,9 @@ class TransformerLayerFn(torch.autograd.Function):
         B, N, D, H, causal, xdtype = ctx.meta
         wqkv, w1, w2 = ctx.weights
         (grads,) = grad_arena(D, 1, g.device)
-        g0, _ = layer_backward(_f32c(g).view(B * N, D), ctx.saved_tensors, wqkv, w1, w2, B, N, H, causal, grads)
+        g0, _ = layer_backward(_f32c(g).view(B * N, D), ctx.saved_tensors, wqkv, w1, w2, B, N, H, causal, grads, drop=ctx.drop)
         join_side(g.device)
-        return (g0.view(B, N, D).to(xdtype), *grads, None, None)
+        return (g0.view(B, N, D).to(xdtype), *grads, None, None, None, None)
 
 
 class TransformerStackFn(torch.autograd.Function):
@@ -259,21 +272,24 @@ class TransformerStackFn(torch.autograd.Function):
     i's fc2 weight/bias gradient, so no separate cast / column-sum passes exist between layers."""
 
     @staticmethod
-    def forward(ctx, x, n_heads, causal, *params):
+    def forward(ctx, x, n_heads, causal, p_attn, p_mlp, *params):
         B, N, D = x.shape
         L = len(params) // 6
         need_grad = any(ctx.needs_input_grad)
         cur = _f32c(x).view(B * N, D)
-        saved_all = []
+        saved_all, drops = [], []
         WEIGHTS.prepare([params[6 * i + j] for i in range(L) for j in (0, 2, 4)], need_grad)
         for i in range(L):
             wqkv, bqkv, w1, b1, w2, b2 = params[6 * i: 6 * i + 6]
-            cur, saved = layer_forward(cur, wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads, causal, need_grad)
+            cur, saved, drop = layer_forward(cur, wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads, causal, need_grad,
+                                             p_attn, p_mlp)
+            drops.append(drop)
             if need_grad:
                 saved_all.extend(saved)
         if need_grad:
             ctx.save_for_backward(*saved_all)
             ctx.params = params
+        ctx.drops = drops
         ctx.meta = (B, N, D, n_heads, causal, L, x.dtype)
         return cur.view(B, N, D).to(x.dtype)
 
@@ -291,14 +307,15 @@ class TransformerStackFn(torch.autograd.Function):
             wqkv, _, w1, _, w2, _ = params[6 * i: 6 * i + 6]
             nxt_db2 = arena[i - 1][5] if i > 0 else None      # layer i's first LN backward feeds layer i-1's fc2 bias grad
             cur, dy2 = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal, arena[i],
-                                      dy2=dy2, have_db2=dy2 is not None, emit_bf16=i > 0, emit_colsum=nxt_db2)
+                                      dy2=dy2, have_db2=dy2 is not None, emit_bf16=i > 0, emit_colsum=nxt_db2,
+                                      drop=ctx.drops[i], emit_dropout=ctx.drops[i - 1][2:] if i > 0 else (0.0, 0))
             if sink is not None:
                 # bucket i is complete now: five gradients from this call, and its fc2 bias gradient was
                 # added by layer i+1's LN1 backward (or by this call's own column sum for the top layer)
                 sink.layer_ready(params, i)
         join_side(cur.device)
         grads = [t for layer in arena for t in layer]
-        return (cur.view(B, N, D).to(xdtype), None, None, *grads)
+        return (cur.view(B, N, D).to(xdtype), None, None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -306,13 +323,14 @@ class TransformerStackFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wqkv, bqkv, n_heads, causal):
+    def forward(ctx, x, wqkv, bqkv, n_heads, causal, p_attn=0.0):
         B, N, D = x.shape
         need_grad = any(ctx.needs_input_grad)
         wb, _ = WEIGHTS.get(wqkv, need_grad)
         xb = ops.cast_bf16(_f32c(x).view(B * N, D))
         qkv = ops.gemm_nt(xb, wb, ops.EPI_BIAS_BF16, bias=_f32c(bqkv))
-        o, lse = ops.attention_fwd(qkv, B, N, n_heads, causal)
+        ctx.drop = (p_attn, new_seed() if p_attn > 0 else 0)
+        o, lse = ops.attention_fwd(qkv, B, N, n_heads, causal, dropout=ctx.drop)
         if need_grad:
             ctx.save_for_backward(xb, qkv, o, lse)
             ctx.wqkv = wqkv
@@ -326,11 +344,11 @@ class AttentionFn(torch.autograd.Function):
         _, wt = WEIGHTS.get(ctx.wqkv, True)
         d_o = ops.cast_bf16(_f32c(g).view(B * N, D))
         db = torch.zeros((3 * D,), dtype=F32, device=g.device)
-        dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=db)
+        dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=db, dropout=ctx.drop)
         dW = torch.empty((3 * D, D), dtype=F32, device=g.device)
         ops.gemm_tn(dqkv, xb, dW, accumulate=False)
         dx = ops.gemm_nt(dqkv, wt, ops.EPI_BIAS_BF16)
-        return dx.view(B, N, D).to(xdtype), dW, db, None, None
+        return dx.view(B, N, D).to(xdtype), dW, db, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

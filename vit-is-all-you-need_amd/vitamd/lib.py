@@ -12,10 +12,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitamd.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c = ctypes
-_P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long
+_P, _I, _F, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_ulonglong
 
 # name -> argtypes ; every function returns int (VITAMD_OK == 0)
 SIGNATURES = {
@@ -26,8 +26,11 @@ SIGNATURES = {
     "vitamd_gemm_tn_ws_bytes": [_I, _I, _I, _I],
     "vitamd_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "vitamd_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
+    "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
+    "vitamd_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],
+    "vitamd_linear_dropout_resid_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P],
+    "vitamd_cast_f32_bf16_dropout": [_P, _P, _L, _F, _U64, _P],
     "vitamd_cast_f32_bf16": [_P, _P, _L, _P],
     "vitamd_cast_transpose_weight": [_P, _P, _P, _I, _I, _P],
     "vitamd_cast_transpose_batched": [_P, _I, _I, _P],

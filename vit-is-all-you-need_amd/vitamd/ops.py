@@ -111,34 +111,37 @@ def layernorm_fwd(x, addend=None):
     return (x_out if addend is not None else x), y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, g_res=None, want_bf16=False, colsum=None):
-    """g = (g_res or 0) + LN'(dy); returns (g fp32, bf16(g) or None)."""
+def layernorm_bwd(dy, x, mean, rstd, g_res=None, want_bf16=False, colsum=None, dropout=(0.0, 0)):
+    """g = (g_res or 0) + LN'(dy); returns (g fp32, bf16(g) or None).  dropout=(p, seed): the bf16 copy
+    also gets that dropout mask (it is then the gradient of a dropped-out Linear output)."""
     _need(dy, BF16, "dy", 2); _need(x, F32, "x", 2)
     M, D = x.shape
     g = torch.empty_like(x)
     gb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
     if g_res is not None:
         _need(g_res, F32, "g_res", 2)
-    code = _L().vitamd_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(g_res), _p(g), _p(gb), _p(colsum), M, D, _stream())
+    code = _L().vitamd_layernorm_bwd_dropout(_p(dy), _p(x), _p(mean), _p(rstd), _p(g_res), _p(g), _p(gb), _p(colsum), M, D,
+                                             float(dropout[0]), int(dropout[1]), _stream())
     _lib.check(code, f"layernorm_bwd[M={M},D={D}]")
     return g, gb
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention_fwd(qkv, B, N, H, causal=False):
-    """qkv bf16 [B*N, 3*H*64] (packed (qkv, head, dh)) -> o bf16 [B*N, H*64], lse2 fp32 [B,H,N]."""
+def attention_fwd(qkv, B, N, H, causal=False, dropout=(0.0, 0)):
+    """qkv bf16 [B*N, 3*H*64] (packed (qkv, head, dh)) -> o bf16 [B*N, H*64], lse2 fp32 [B,H,N].
+    dropout=(p, seed): dropout on the softmax probabilities."""
     _need(qkv, BF16, "qkv", 2)
     D = H * 64
     if tuple(qkv.shape) != (B * N, 3 * D):
         raise _lib.VitamdError("attention_fwd: qkv must be [B*N, 3*H*64] (head_dim 64 only)")
     o = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=F32, device=qkv.device)
-    code = _L().vitamd_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, H, 64, int(causal), _stream())
+    code = _L().vitamd_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, H, 64, int(causal), float(dropout[0]), int(dropout[1]), _stream())
     _lib.check(code, f"attention_fwd[B={B},N={N},H={H}]")
     return o, lse
 
 
-def attention_bwd(qkv, o, lse, d_o, B, N, H, causal=False, dbias=None):
+def attention_bwd(qkv, o, lse, d_o, B, N, H, causal=False, dbias=None, dropout=(0.0, 0)):
     """dqkv bf16 [B*N, 3*H*64]; the column sums of dqkv (QKV bias gradient) are added to `dbias` if given."""
     _need(qkv, BF16, "qkv", 2); _need(o, BF16, "o", 2); _need(d_o, BF16, "d_o", 2); _need(lse, F32, "lse")
     if dbias is not None:
@@ -146,12 +149,31 @@ def attention_bwd(qkv, o, lse, d_o, B, N, H, causal=False, dbias=None):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     code = _L().vitamd_attention_bwd(_p(qkv), _p(o), _p(lse), _p(d_o), _p(dqkv), _p(delta), _p(dbias), B, N, H, 64, int(causal),
-                                     _stream())
+                                     float(dropout[0]), int(dropout[1]), _stream())
     _lib.check(code, f"attention_bwd[B={B},N={N},H={H}]")
     return dqkv
 
 
+def linear_dropout_resid(a, b, bias, resid, dropout):
+    """out f32 = resid + dropout_p(bf16(a @ b^T + bias)); dropout = (p, seed)."""
+    _need(a, BF16, "a", 2); _need(b, BF16, "b", 2); _need(resid, F32, "resid", 2); _need(bias, F32, "bias", 1)
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), dtype=F32, device=a.device)
+    code = _L().vitamd_linear_dropout_resid_bf16(_p(a), _p(b), _p(out), _p(bias), _p(resid), M, N, K, float(dropout[0]), int(dropout[1]),
+                                                 _stream())
+    _lib.check(code, f"linear_dropout_resid[M={M},N={N},K={K}]")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ helpers
+def cast_bf16_dropout(x, dropout):
+    _need(x, F32, "x")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.check(_L().vitamd_cast_f32_bf16_dropout(_p(x), _p(out), x.numel(), float(dropout[0]), int(dropout[1]), _stream()), "cast_dropout")
+    return out
+
+
 def cast_bf16(x):
     _need(x, F32, "x")
     out = torch.empty(x.shape, dtype=BF16, device=x.device)
