@@ -55,6 +55,8 @@ class WeightCache:
         return ent
 
     def get(self, w: torch.Tensor, want_t: bool):
+        if not w.is_cuda:
+            raise ops._lib.VitamdError("weight: expected a ROCm device tensor (the HIP kernels are the only implementation)")
         ent = self._c.get(id(w))
         if self._fresh(ent, w, want_t):
             return ent["wb"], ent["wbt"]
@@ -69,6 +71,8 @@ class WeightCache:
 
     def prepare(self, weights, want_t: bool):
         """make every weight in the list fresh with one batched launch (no-op when they all are)"""
+        for w in weights:
+            ops._need(w.detach(), F32, "weight")          # device / dtype / contiguity: fail loudly, no fallback
         if all(self._fresh(self._c.get(id(w)), w, want_t) for w in weights):
             return
         import numpy as np
