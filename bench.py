@@ -130,10 +130,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local % ndev)       # (a rehearsal on a 1-GPU box may run several ranks on one card)
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("VITAMD_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import train_vit as TV
     from vitamd.ddp import DataParallel
