@@ -77,6 +77,15 @@ int vitamd_layernorm_bwd_dropout(const void* dy_bf16, const float* x, const floa
                                  const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D,
                                  float dropout_p, unsigned long long seed, void* stream);
 
+/* Affine LayerNorm (nn.LayerNorm weight/bias) for the `blocks.py` surface (blocks.py:43,48,179,184).
+ * forward: y = bf16(LN(x) * gamma + beta).  backward: g_out = (g_res or 0) + dLN/dx; dgamma, dbeta are
+ * ACCUMULATED into (zero them first); optional bf16 copy of g_out and its column sums as above. */
+int vitamd_layernorm_affine_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                                float* rstd, int M, int D, float eps, void* stream);
+int vitamd_layernorm_affine_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                const float* gamma, const float* g_res, float* g_out, void* g_bf16, float* colsum,
+                                float* dgamma, float* dbeta, int M, int D, void* stream);
+
 /* ---- Attention on the packed fused-QKV layout ------------------------------------------------
  * qkv bf16 [B,N,3,H,64] (output-channel order (qkv, head, dh) of transformer.py:27), o bf16 [B,N,H*64],
  * lse2 fp32 [B,H,N].  head_dim must be 64, N <= 512.  causal != 0 applies the strictly-upper -inf

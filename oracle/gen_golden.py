@@ -276,6 +276,55 @@ def gen_tokenizer_fixtures():
                            "latent_dim": 12, "preset": "B", "n_layers": 12, "n_embd": 768})
 
 
+BLOCK_CASES = {
+    # name: (class, ctor kwargs, input kind)
+    "rab": ("ResidualAttentionBlock", dict(d_model=128, n_head=2), "lnd"),
+    "rab_nomlp": ("ResidualAttentionBlock", dict(d_model=128, n_head=2, mlp_ratio=0), "lnd"),
+    "uvit_skip": ("UViTBlock", dict(dim=128, num_heads=2, skip=True), "nld_skip"),
+    "uvit_bias": ("UViTBlock", dict(dim=128, num_heads=2, qkv_bias=True), "nld"),
+    "attn": ("Attention", dict(dim=128, num_heads=2, qkv_bias=True), "nld"),
+    "mlp": ("Mlp", dict(in_features=128, hidden_features=512), "nld"),
+}
+
+
+def gen_blocks_fixture():
+    """the reference's blocks.py classes (fp32 CPU) on seeded inputs."""
+    import blocks as RB   # the reference's module (torch + einops only)
+    out = {}
+    for name, (cls, kw, kind) in BLOCK_CASES.items():
+        seed = 50 + len(out)
+        m = getattr(RB, cls)(**kw)
+        shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(W.module_state(seed, shapes), strict=True)
+        L, N, D = 37, 3, 128
+        x = W.normal(seed, "x", (L, N, D) if kind == "lnd" else (N, L, D)).requires_grad_(True)
+        dy = W.normal(seed, "dy", tuple(x.shape))
+        args = [x]
+        if kind == "nld_skip":
+            skip = W.normal(seed, "skip", (N, L, D)).requires_grad_(True)
+            args.append(skip)
+
+        def run(bf16):
+            m.zero_grad(set_to_none=True)
+            for a in args:
+                a.grad = None
+            if bf16:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    y = m(*args)
+            else:
+                y = m(*args)
+            (y.float() * dy).sum().backward()
+            return (y.detach().float(), [a.grad.clone() for a in args], {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+
+        y, dxs, grads = run(False)
+        y16, dx16, g16 = run(True)
+        out[name] = {"seed": seed, "shapes": shapes, "y": y, "dx": dxs[0], "dskip": dxs[1] if len(dxs) > 1 else None,
+                     "grads": grads,
+                     "ref_bf16_floor": {"y": rel_l2(y16, y), "dx": rel_l2(dx16[0], dxs[0]), "grads": {k: rel_l2(g16[k], grads[k]) for k in grads}}}
+        out[name] = {k: v for k, v in out[name].items() if v is not None}
+    save("blocks_tiny.pt", out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -286,6 +335,7 @@ def main():
     gen_lr_fixture(RU)
     gen_train_steps_fixture(TV, RU)
     gen_tokenizer_fixtures()
+    gen_blocks_fixture()
 
 
 if __name__ == "__main__":

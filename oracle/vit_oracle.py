@@ -256,6 +256,50 @@ def tokenizer_forward(images, sd, enc, quant, dec, enc_cfg: OracleViTConfig, dec
 
 
 # --------------------------------------------------------------------------------------
+# blocks.py surface: affine LayerNorm, attention with output projection
+# --------------------------------------------------------------------------------------
+def layer_norm_affine(x, w, b):
+    """nn.LayerNorm(d) with weight/bias, eps 1e-5 (reference blocks.py:43,48,179,184)."""
+    return layer_norm(x) * w + b
+
+
+def attention_proj(x, wqkv, bqkv, wo, bo, n_heads, lowp=False):
+    """qkv Linear -> SDPA -> output projection, batch-first [B,N,D]: reference blocks.Attention
+    (blocks.py:95-121) and nn.MultiheadAttention as used by blocks.py:56-60 (same (qkv, head, dh) packing)."""
+    qkv = linear(x, wqkv, bqkv, lowp)
+    q, k, v = split_qkv(qkv, n_heads)
+    o = sdpa(q, k, v, False, lowp)
+    B, H, N, dh = o.shape
+    return linear(o.permute(0, 2, 1, 3).reshape(B, N, H * dh), wo, bo, lowp)
+
+
+def mlp2(x, w1, b1, w2, b2, lowp=False):
+    """fc1 -> erf-GELU -> fc2 (reference blocks.Mlp blocks.py:165-171; mlp c_fc/gelu/c_proj blocks.py:50-54)."""
+    return linear(gelu_erf(linear(x, w1, b1, lowp), lowp), w2, b2, lowp)
+
+
+def residual_attention_block(x_lnd, sd, n_heads, lowp=False):
+    """Reference blocks.ResidualAttentionBlock.forward (blocks.py:62-70) on sequence-first [L,N,D] input."""
+    x = x_lnd.transpose(0, 1)
+    x = x + attention_proj(layer_norm_affine(x, sd["ln_1.weight"], sd["ln_1.bias"]), sd["attn.in_proj_weight"], sd["attn.in_proj_bias"],
+                           sd["attn.out_proj.weight"], sd["attn.out_proj.bias"], n_heads, lowp)
+    if "mlp.c_fc.weight" in sd:
+        x = x + mlp2(layer_norm_affine(x, sd["ln_2.weight"], sd["ln_2.bias"]), sd["mlp.c_fc.weight"], sd["mlp.c_fc.bias"],
+                     sd["mlp.c_proj.weight"], sd["mlp.c_proj.bias"], lowp)
+    return x.transpose(0, 1)
+
+
+def uvit_block(x, sd, n_heads, skip=None, lowp=False):
+    """Reference blocks.UViTBlock._forward (blocks.py:196-201)."""
+    if skip is not None:
+        x = linear(torch.cat([x, skip], dim=-1), sd["skip_linear.weight"], sd["skip_linear.bias"], lowp).float()
+    x = x + attention_proj(layer_norm_affine(x, sd["norm1.weight"], sd["norm1.bias"]), sd["attn.qkv.weight"], sd.get("attn.qkv.bias"),
+                           sd["attn.proj.weight"], sd["attn.proj.bias"], n_heads, lowp)
+    return x + mlp2(layer_norm_affine(x, sd["norm2.weight"], sd["norm2.bias"]), sd["mlp.fc1.weight"], sd["mlp.fc1.bias"],
+                    sd["mlp.fc2.weight"], sd["mlp.fc2.bias"], lowp)
+
+
+# --------------------------------------------------------------------------------------
 # LR schedule (reference utils.py:5-9), closed form
 # --------------------------------------------------------------------------------------
 def lr_at(step: int, base_lr: float, warmup_steps: int, train_steps: int, min_lr: float) -> float:

@@ -98,3 +98,19 @@ def tokenizer_state(seed, enc, quant, dec, image_patches, latent_tokens, enc_ext
     ep[dec + "embd_proj.weight"] = ep[dec + "embd_proj.weight"].reshape(3 * patch * patch, D, 1, 1)  # Conv2d(k=1) weight
     sd.update(ep)
     return sd
+
+
+def module_state(seed, shapes: dict) -> dict:
+    """Generic deterministic parameters for a module given {key: shape}: LayerNorm-style vectors named
+    '*ln*'/'*norm*' get weight = 1 + 0.2 N(0,1), bias = 0.1 N(0,1) (so the affine part is exercised);
+    everything else N(0, 0.05)."""
+    sd = {}
+    for k, shape in shapes.items():
+        is_norm = any(t in k for t in ("ln_", "norm"))
+        if is_norm and k.endswith("weight"):
+            sd[k] = 1.0 + normal(seed, k, tuple(shape), 0.2)
+        elif is_norm:
+            sd[k] = normal(seed, k, tuple(shape), 0.1)
+        else:
+            sd[k] = normal(seed, k, tuple(shape), 0.05)
+    return sd

@@ -289,3 +289,47 @@ def test_single_layer_presets_vs_oracle(hip, preset, seq, batch):
     assert O.rel_l2(xg.grad.cpu(), go[0]) < 1e-2
     for (k, p), gk in zip(m.named_parameters(), go[1:]):
         assert O.rel_l2(p.grad.cpu(), gk) < 1.5e-2, k
+
+
+# ------------------------------------------------------------------ blocks.py surface
+BLOCK_CTORS = {
+    "rab": ("ResidualAttentionBlock", dict(d_model=128, n_head=2)),
+    "rab_nomlp": ("ResidualAttentionBlock", dict(d_model=128, n_head=2, mlp_ratio=0)),
+    "uvit_skip": ("UViTBlock", dict(dim=128, num_heads=2, skip=True)),
+    "uvit_bias": ("UViTBlock", dict(dim=128, num_heads=2, qkv_bias=True)),
+    "attn": ("Attention", dict(dim=128, num_heads=2, qkv_bias=True)),
+    "mlp": ("Mlp", dict(in_features=128, hidden_features=512)),
+}
+
+
+@pytest.mark.parametrize("name", list(BLOCK_CTORS))
+def test_blocks_surface_vs_reference_golden(hip, name):
+    import blocks as BK
+    from test_oracle import blocks_oracle_run
+    case = load_golden("blocks_tiny.pt")[name]
+    cls, kw = BLOCK_CTORS[name]
+    m = getattr(BK, cls)(**kw)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == case["shapes"]       # checkpoint-key contract
+    m.load_state_dict(W.module_state(case["seed"], case["shapes"]), strict=True)
+    m = m.cuda()
+    L, N, D = 37, 3, 128
+    lnd = name.startswith("rab")
+    x = W.normal(case["seed"], "x", (L, N, D) if lnd else (N, L, D)).cuda().requires_grad_(True)
+    dy = W.normal(case["seed"], "dy", tuple(x.shape)).cuda()
+    args = [x]
+    if name == "uvit_skip":
+        args.append(W.normal(case["seed"], "skip", (N, L, D)).cuda().requires_grad_(True))
+    y = m(*args)
+    (y * dy).sum().backward()
+    torch.cuda.synchronize()
+    floor = case["ref_bf16_floor"]
+    assert O.rel_l2(y.detach().cpu(), case["y"]) < 2 * floor["y"] + 2e-3
+    assert O.rel_l2(x.grad.cpu(), case["dx"]) < 2 * floor["dx"] + 4e-3
+    if "dskip" in case:
+        assert O.rel_l2(args[1].grad.cpu(), case["dskip"]) < 2e-2
+    for k, p in m.named_parameters():
+        assert O.rel_l2(p.grad.cpu(), case["grads"][k]) < 2 * floor["grads"][k] + 6e-3, k
+    # tight: against the oracle's bf16-flow emulation of the same block
+    lo = blocks_oracle_run(name, case, lowp=True)
+    assert O.rel_l2(y.detach().cpu(), lo["y"]) < 5e-3
+    assert O.rel_l2(x.grad.cpu(), lo["dx"]) < 1.2e-2

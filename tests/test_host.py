@@ -114,3 +114,19 @@ def test_tokenizer_surfaces_match_reference_checkpoints():
     assert sorted(v.state_dict().keys()) == g["state_keys"] and sum(p.numel() for p in v.parameters()) == g["n_params"] == 158_069_772
     assert {k: list(t.shape) for k, t in v.state_dict().items()} == g["state_shapes"]
     assert float(m.quant.codebook.weight.abs().max()) <= 1.0 / 2048 + 1e-9          # reference init (train_titok.py:49)
+
+
+def test_blocks_surface_state_dict_contract():
+    import blocks as BK
+    g = load_golden("blocks_tiny.pt")
+    ctors = {"rab": ("ResidualAttentionBlock", dict(d_model=128, n_head=2)), "rab_nomlp": ("ResidualAttentionBlock", dict(d_model=128, n_head=2, mlp_ratio=0)),
+             "uvit_skip": ("UViTBlock", dict(dim=128, num_heads=2, skip=True)), "uvit_bias": ("UViTBlock", dict(dim=128, num_heads=2, qkv_bias=True)),
+             "attn": ("Attention", dict(dim=128, num_heads=2, qkv_bias=True)), "mlp": ("Mlp", dict(in_features=128, hidden_features=512))}
+    for name, (cls, kw) in ctors.items():
+        m = getattr(BK, cls)(**kw)
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == g[name]["shapes"], name
+    assert isinstance(BK.ATTENTION_MODE, str)
+    with pytest.raises(NotImplementedError):
+        BK.UViTBlock(128, 2, drop_path=0.1)
+    with pytest.raises(NotImplementedError):
+        BK.Attention(96, 2)            # head_dim 48

@@ -146,3 +146,43 @@ def test_tokenizers_match_reference():
                 assert gr is None or gr.numel() == 0 or float(gr.abs().max()) == 0.0, k
             else:
                 assert _err(gr, ref) < 2e-4, k
+
+
+# ------------------------------------------------------------------ blocks.py surface
+def blocks_oracle_run(name, case, lowp=False):
+    sd = W.module_state(case["seed"], case["shapes"])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    L, N, D = 37, 3, 128
+    lnd = name.startswith("rab")
+    x = W.normal(case["seed"], "x", (L, N, D) if lnd else (N, L, D)).requires_grad_(True)
+    dy = W.normal(case["seed"], "dy", tuple(x.shape))
+    skip = None
+    if name == "uvit_skip":
+        skip = W.normal(case["seed"], "skip", (N, L, D)).requires_grad_(True)
+    if lnd:
+        y = O.residual_attention_block(x, leaves, 2, lowp)
+    elif name.startswith("uvit"):
+        y = O.uvit_block(x, leaves, 2, skip, lowp)
+    elif name == "attn":
+        y = O.attention_proj(x, leaves["qkv.weight"], leaves["qkv.bias"], leaves["proj.weight"], leaves["proj.bias"], 2, lowp)
+    else:
+        y = O.mlp2(x, leaves["fc1.weight"], leaves["fc1.bias"], leaves["fc2.weight"], leaves["fc2.bias"], lowp)
+    wrt = [x] + ([skip] if skip is not None else []) + list(leaves.values())
+    grads = torch.autograd.grad((y * dy).sum(), wrt)
+    out = {"y": y.detach(), "dx": grads[0], "grads": dict(zip(leaves.keys(), grads[-len(leaves):]))}
+    if skip is not None:
+        out["dskip"] = grads[1]
+    return out
+
+
+def test_blocks_oracle_matches_reference():
+    g = load_golden("blocks_tiny.pt")
+    assert set(g) == {"rab", "rab_nomlp", "uvit_skip", "uvit_bias", "attn", "mlp"}
+    for name, case in g.items():
+        got = blocks_oracle_run(name, case)
+        assert O.rel_l2(got["y"], case["y"]) < 3e-6, name
+        assert O.rel_l2(got["dx"], case["dx"]) < 1e-5, name
+        if "dskip" in case:
+            assert O.rel_l2(got["dskip"], case["dskip"]) < 1e-5, name
+        for k, ref in case["grads"].items():
+            assert O.rel_l2(got["grads"][k], ref) < 2e-5, (name, k)

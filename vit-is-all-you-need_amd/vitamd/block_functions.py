@@ -1,0 +1,166 @@
+"""autograd glue for the `blocks.py` surface of the reference: pre-LN blocks with
+AFFINE LayerNorm and an attention OUTPUT projection (blocks.ResidualAttentionBlock, blocks.UViTBlock),
+stand-alone blocks.Attention and blocks.Mlp.  Same kernels and the same bf16 dtype flow as
+vitamd/functions.py (fp32 residual stream, bf16 GEMM / attention operands, fp32 parameter gradients).
+Not on the measured ViT path; kept apart from functions.py so that path stays untouched."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .functions import WEIGHTS, _f32c
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _zeros(n, dev):
+    return torch.zeros((n,), dtype=F32, device=dev)
+
+
+class BlockFn(torch.autograd.Function):
+    """x = x + proj(attn(LN1(x))) ; x = x + fc2(gelu(fc1(LN2(x))))   (reference blocks.py:62-70, 193-201)."""
+
+    @staticmethod
+    def forward(ctx, x, g1, be1, wqkv, bqkv, wo, bo, g2, be2, w1, b1, w2, b2, n_heads, has_mlp):
+        B, N, D = x.shape
+        H = n_heads
+        x0 = _f32c(x).view(B * N, D)
+        wqkv_b, _ = WEIGHTS.get(wqkv, True)
+        wo_b, _ = WEIGHTS.get(wo, True)
+        a, mean1, rstd1 = ops.layernorm_affine_fwd(x0, _f32c(g1), _f32c(be1))
+        qkv = ops.gemm_nt(a, wqkv_b, ops.EPI_BIAS_BF16, bias=_f32c(bqkv) if bqkv is not None else None)
+        o, lse = ops.attention_fwd(qkv, B, N, H, False)
+        x1 = ops.gemm_nt(o, wo_b, ops.EPI_RESID_F32, bias=_f32c(bo), aux=x0)          # out-projection + residual
+        saved = [x0, mean1, rstd1, a, qkv, o, lse, x1]
+        out = x1
+        if has_mlp:
+            w1_b, _ = WEIGHTS.get(w1, True)
+            w2_b, _ = WEIGHTS.get(w2, True)
+            bln, mean2, rstd2 = ops.layernorm_affine_fwd(x1, _f32c(g2), _f32c(be2))
+            pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU, bias=_f32c(b1))
+            out = ops.gemm_nt(h, w2_b, ops.EPI_RESID_F32, bias=_f32c(b2), aux=x1)
+            saved += [mean2, rstd2, bln, pre, h]
+        ctx.save_for_backward(*saved)
+        ctx.params = (g1, wqkv, bqkv, wo, g2, w1, w2)
+        ctx.meta = (B, N, D, H, has_mlp, x.dtype)
+        return out.view(B, N, D).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D, H, has_mlp, xdtype = ctx.meta
+        g1p, wqkv, bqkv, wo, g2p, w1, w2 = ctx.params
+        sv = ctx.saved_tensors
+        x0, mean1, rstd1, a, qkv, o, lse, x1 = sv[:8]
+        dev = g.device
+        gcur = _f32c(g).view(B * N, D)
+        dW1 = db1 = dW2 = db2 = dg2 = dbe2 = None
+        if has_mlp:
+            mean2, rstd2, bln, pre, h = sv[8:]
+            Dh = h.shape[1]
+            _, w1_t = WEIGHTS.get(w1, True)
+            _, w2_t = WEIGHTS.get(w2, True)
+            dy2 = ops.cast_bf16(gcur)
+            db2 = ops.colsum(dy2)
+            dW2 = torch.empty((D, Dh), dtype=F32, device=dev)
+            ops.gemm_tn(dy2, h, dW2, accumulate=False)
+            db1 = _zeros(Dh, dev)
+            dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)
+            dW1 = torch.empty((Dh, D), dtype=F32, device=dev)
+            ops.gemm_tn(dpre, bln, dW1, accumulate=False)
+            dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)
+            dg2, dbe2 = _zeros(D, dev), _zeros(D, dev)
+            dbo = _zeros(D, dev)
+            gcur, dyo = ops.layernorm_affine_bwd(dbln, x1, mean2, rstd2, _f32c(g2p), dg2, dbe2, g_res=gcur, want_bf16=True, colsum=dbo)
+        else:
+            dyo = ops.cast_bf16(gcur)
+            dbo = ops.colsum(dyo)
+        # ---- attention with output projection
+        _, wo_t = WEIGHTS.get(wo, True)
+        _, wqkv_t = WEIGHTS.get(wqkv, True)
+        dWo = torch.empty((D, D), dtype=F32, device=dev)
+        ops.gemm_tn(dyo, o, dWo, accumulate=False)
+        d_o = ops.gemm_nt(dyo, wo_t, ops.EPI_BIAS_BF16)
+        dbqkv = _zeros(3 * D, dev)
+        dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, False, dbias=dbqkv)
+        dWqkv = torch.empty((3 * D, D), dtype=F32, device=dev)
+        ops.gemm_tn(dqkv, a, dWqkv, accumulate=False)
+        da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)
+        dg1, dbe1 = _zeros(D, dev), _zeros(D, dev)
+        g0, _ = ops.layernorm_affine_bwd(da, x0, mean1, rstd1, _f32c(g1p), dg1, dbe1, g_res=gcur)
+        return (g0.view(B, N, D).to(xdtype), dg1, dbe1, dWqkv, dbqkv if bqkv is not None else None, dWo, dbo, dg2, dbe2,
+                dW1, db1, dW2, db2, None, None)
+
+
+class AttnProjFn(torch.autograd.Function):
+    """proj(attention(qkv(x)))  — reference blocks.Attention (blocks.py:84-121), dropout-free."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, wo, bo, n_heads):
+        B, N, D = x.shape
+        xb = ops.cast_bf16(_f32c(x).view(B * N, D))
+        wqkv_b, _ = WEIGHTS.get(wqkv, True)
+        wo_b, _ = WEIGHTS.get(wo, True)
+        qkv = ops.gemm_nt(xb, wqkv_b, ops.EPI_BIAS_BF16, bias=_f32c(bqkv) if bqkv is not None else None)
+        o, lse = ops.attention_fwd(qkv, B, N, n_heads, False)
+        y = ops.gemm_nt(o, wo_b, ops.EPI_BIAS_BF16, bias=_f32c(bo))
+        ctx.save_for_backward(xb, qkv, o, lse)
+        ctx.params = (wqkv, bqkv, wo)
+        ctx.meta = (B, N, D, n_heads, x.dtype)
+        return y.view(B, N, D).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D, H, xdtype = ctx.meta
+        wqkv, bqkv, wo = ctx.params
+        xb, qkv, o, lse = ctx.saved_tensors
+        dev = g.device
+        dy = ops.cast_bf16(_f32c(g).view(B * N, D))
+        dbo = ops.colsum(dy)
+        _, wo_t = WEIGHTS.get(wo, True)
+        _, wqkv_t = WEIGHTS.get(wqkv, True)
+        dWo = torch.empty((D, D), dtype=F32, device=dev)
+        ops.gemm_tn(dy, o, dWo, accumulate=False)
+        d_o = ops.gemm_nt(dy, wo_t, ops.EPI_BIAS_BF16)
+        dbqkv = _zeros(3 * D, dev)
+        dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, False, dbias=dbqkv)
+        dWqkv = torch.empty((3 * D, D), dtype=F32, device=dev)
+        ops.gemm_tn(dqkv, xb, dWqkv, accumulate=False)
+        dx = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)
+        return dx.view(B, N, D).to(xdtype), dWqkv, dbqkv if bqkv is not None else None, dWo, dbo, None
+
+
+class MlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x)))  — reference blocks.Mlp (blocks.py:155-171), dropout-free."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        lead, K = x.shape[:-1], x.shape[-1]
+        xb = ops.cast_bf16(_f32c(x).reshape(-1, K))
+        w1_b, _ = WEIGHTS.get(w1, True)
+        w2_b, _ = WEIGHTS.get(w2, True)
+        pre, h = ops.gemm_nt(xb, w1_b, ops.EPI_GELU, bias=_f32c(b1))
+        y = ops.gemm_nt(h, w2_b, ops.EPI_BIAS_BF16, bias=_f32c(b2))
+        ctx.save_for_backward(xb, pre, h)
+        ctx.params = (w1, w2)
+        ctx.meta = (lead, K, x.dtype)
+        return y.view(*lead, w2.shape[0]).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        lead, K, xdtype = ctx.meta
+        w1, w2 = ctx.params
+        xb, pre, h = ctx.saved_tensors
+        dev = g.device
+        Dh, Dout = h.shape[1], w2.shape[0]
+        dy = ops.cast_bf16(_f32c(g).reshape(-1, Dout))
+        db2 = ops.colsum(dy)
+        _, w1_t = WEIGHTS.get(w1, True)
+        _, w2_t = WEIGHTS.get(w2, True)
+        dW2 = torch.empty((Dout, Dh), dtype=F32, device=dev)
+        ops.gemm_tn(dy, h, dW2, accumulate=False)
+        db1 = _zeros(Dh, dev)
+        dpre = ops.gemm_nt(dy, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)
+        dW1 = torch.empty((Dh, K), dtype=F32, device=dev)
+        ops.gemm_tn(dpre, xb, dW1, accumulate=False)
+        dx = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)
+        return dx.view(*lead, K).to(xdtype), dW1, db1, dW2, db2

@@ -26,6 +26,8 @@ SIGNATURES = {
     "vitamd_gemm_tn_ws_bytes": [_I, _I, _I, _I],
     "vitamd_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "vitamd_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vitamd_layernorm_affine_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "vitamd_layernorm_affine_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],

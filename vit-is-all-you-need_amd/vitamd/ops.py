@@ -126,6 +126,30 @@ def layernorm_bwd(dy, x, mean, rstd, g_res=None, want_bf16=False, colsum=None, d
     return g, gb
 
 
+def layernorm_affine_fwd(x, gamma, beta, eps=LN_EPS):
+    """x fp32 [M,D] -> (y bf16 = LN(x)*gamma+beta, mean, rstd)."""
+    _need(x, F32, "x", 2); _need(gamma, F32, "gamma", 1); _need(beta, F32, "beta", 1)
+    M, D = x.shape
+    y = torch.empty((M, D), dtype=BF16, device=x.device)
+    mean = torch.empty((M,), dtype=F32, device=x.device)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    _lib.check(_L().vitamd_layernorm_affine_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, float(eps), _stream()),
+               "layernorm_affine_fwd")
+    return y, mean, rstd
+
+
+def layernorm_affine_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, g_res=None, want_bf16=False, colsum=None):
+    """returns (g fp32, bf16(g) or None); dgamma / dbeta (fp32 [D]) are accumulated into."""
+    _need(dy, BF16, "dy", 2); _need(x, F32, "x", 2); _need(gamma, F32, "gamma", 1)
+    _need(dgamma, F32, "dgamma", 1); _need(dbeta, F32, "dbeta", 1)
+    M, D = x.shape
+    g = torch.empty_like(x)
+    gb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    _lib.check(_L().vitamd_layernorm_affine_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g_res), _p(g), _p(gb), _p(colsum),
+                                                _p(dgamma), _p(dbeta), M, D, _stream()), "layernorm_affine_bwd")
+    return g, gb
+
+
 # ------------------------------------------------------------------------------------------ attention
 def attention_fwd(qkv, B, N, H, causal=False, dropout=(0.0, 0)):
     """qkv bf16 [B*N, 3*H*64] (packed (qkv, head, dh)) -> o bf16 [B*N, H*64], lse2 fp32 [B,H,N].
