@@ -85,6 +85,12 @@ int vitamd_layernorm_affine_fwd(const float* x, const float* gamma, const float*
 int vitamd_layernorm_affine_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* g_res, float* g_out, void* g_bf16, float* colsum,
                                 float* dgamma, float* dbeta, int M, int D, void* stream);
+/* fp32-in / fp32-out forms for a LayerNorm that is NOT followed by a GEMM: the tokenizers' ln_pre / ln_post
+ * (blocks.py:247,253 / :320,326), whose output stays in the fp32 token stream.  dgamma / dbeta accumulated into. */
+int vitamd_layernorm_affine_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                    float* rstd, int M, int D, float eps, void* stream);
+int vitamd_layernorm_affine_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, float* g_out, float* dgamma, float* dbeta, int M, int D, void* stream);
 
 /* ---- Attention on the packed fused-QKV layout ------------------------------------------------
  * qkv bf16 [B,N,3,H,64] (output-channel order (qkv, head, dh) of transformer.py:27), o bf16 [B,N,H*64],
@@ -124,9 +130,21 @@ int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void* dyp_bf16,
                      int seq, int extra, int D, void* stream);
 
 /* ---- VQ quantiser (TiTok / ViT-VQGAN) --------------------------------------
- * idx[m] = argmin_k ||x[m,:] - codebook[k,:]||^2, first minimum, fp32; d <= 64; idx is int64.
- * replaces train_titok.py:53 / train_vit_vqgan.py:52 `torch.cdist(x, embedding).argmin(dim=-1)`. */
+ * idx[m] = argmin_k ||x[m,:] - codebook[k,:]||^2, first minimum, fp32; d <= 1024; idx is int64.
+ * replaces train_titok.py:53 / train_vit_vqgan.py:52 `torch.cdist(x, embedding).argmin(dim=-1)` and the
+ * expanded-distance argmin of blocks.py:442-446 (blocks.VectorQuantizer). */
 int vitamd_vq_nearest(const float* x, const float* codebook, long long* idx, int M, int K, int d, void* stream);
+
+/* ---- 3x3 smoothing convolution of the pixel decoders (blocks.py surface) ----
+ * NCHW fp32, stride 1, zero padding 1, Cin = Cout = 3 (anything else: VITAMD_ERR_SHAPE).
+ * w [Cout,Cin,3,3], bias [Cout] or null.  replaces `self.conv_out = nn.Conv2d(3, 3, 3, padding=1)`
+ * (blocks.py:333, applied at :355 and :402).
+ * bwd: dx (or null) = input gradient, overwritten; dw [Cout,Cin,3,3] (or null) and db [Cout] (or null) are
+ * ACCUMULATED into (atomics): zero them for a fresh gradient. */
+int vitamd_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                       void* stream);
+int vitamd_conv3x3_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int Cin,
+                       int Cout, int H, int W, void* stream);
 
 /* ---- optimiser -------------------------------------------------------------------------------
  * One fused AdamW update (decoupled weight decay, bias correction for 1-based `step`) of n fp32

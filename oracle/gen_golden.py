@@ -325,6 +325,87 @@ def gen_blocks_fixture():
     save("blocks_tiny.pt", out)
 
 
+TOK_CFG = dict(image_size=32, patch_size=8, transformer="small", latent_tokens=8, latent_dim=12, text_context_length=5, text_embed_dim=64)
+VQ_CASES = {
+    # name: (ctor kwargs, z shape)
+    "plain": (dict(codebook_size=256, token_size=12), (4, 12, 4, 8)),
+    "l2norm": (dict(codebook_size=256, token_size=12, use_l2_norm=True), (4, 12, 4, 8)),
+    "wide": (dict(), (2, 256, 1, 16)),                                    # the class defaults: 1024 codes x 256
+    "cluster": (dict(codebook_size=64, token_size=12, clustering_vq=True), (4, 12, 4, 8)),
+}
+
+
+def _grads_summary(named):
+    return {k: summarize(g) for k, g in named.items()}
+
+
+def gen_block_tokenizer_fixture():
+    """blocks.TiTokEncoder / TiTokDecoder / TATiTokDecoder / VectorQuantizer (blocks.py:208-505),
+    reference fp32 CPU forward + backward on seeded inputs.  `config` is a plain namespace (the classes only read
+    attributes, and `.model.vq_model.get`)."""
+    import blocks as RB
+    from types import SimpleNamespace as NS
+    c = TOK_CFG
+    cfg = NS(image_size=c["image_size"], patch_size=c["patch_size"], transformer=c["transformer"], latent_tokens=c["latent_tokens"],
+             latent_dim=c["latent_dim"], model=NS(vq_model={"text_context_length": c["text_context_length"], "text_embed_dim": c["text_embed_dim"]}))
+    B = 3
+    out = {"config": dict(c), "batch": B}
+    width = 512
+
+    def case(name, cls, seed, make_inputs):
+        m = getattr(RB, cls)(cfg)
+        shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(W.module_state(seed, shapes), strict=True)
+        inputs = make_inputs(seed)
+
+        def run(bf16):
+            m.zero_grad(set_to_none=True)
+            args = [a.detach().clone().requires_grad_(True) for a in inputs]
+            if bf16:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    y = m(*args)
+            else:
+                y = m(*args)
+            dy = W.normal(seed, "dy", tuple(y.shape))
+            (y.float() * dy).sum().backward()
+            return y.detach().float(), [a.grad.detach().clone() for a in args], {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+        y, dins, grads = run(False)
+        y16, d16, g16 = run(True)
+        out[name] = {"seed": seed, "shapes": shapes, "y": summarize(y), "dinputs": [summarize(d) for d in dins], "grads": _grads_summary(grads),
+                     "ref_bf16_floor": {"y": rel_l2(y16, y), "dinputs": [rel_l2(a, b) for a, b in zip(d16, dins)],
+                                        "grads_max": max(rel_l2(g16[k], grads[k]) for k in grads)}}
+
+    lat, ldim = c["latent_tokens"], c["latent_dim"]
+    case("encoder", "TiTokEncoder", 71, lambda s: [W.normal(s, "pixels", (B, 3, 32, 32)), W.normal(s, "latent_tokens", (lat, width), 0.05)])
+    case("decoder", "TiTokDecoder", 72, lambda s: [W.normal(s, "zq", (B, ldim, 1, lat))])
+    case("tatitok_decoder", "TATiTokDecoder", 73, lambda s: [W.normal(s, "zq", (B, ldim, 1, lat)),
+                                                              W.normal(s, "text", (B, c["text_context_length"], c["text_embed_dim"]))])
+
+    RB.gather = lambda t: t   # the reference never defines `gather` (blocks.py:457): single-process meaning
+    for name, (kw, zshape) in VQ_CASES.items():
+        seed = 80 + len([k for k in out if k.startswith("vq_")])
+        m = RB.VectorQuantizer(**kw)
+        shapes = {k: list(v.shape) for k, v in m.state_dict().items() if k != "embed_prob"}
+        sd = W.module_state(seed, shapes)
+        m.load_state_dict(sd, strict=False)
+        m.train()
+        z = (W.normal(seed, "z", zshape) * 0.05).requires_grad_(True)
+        code0 = m.embedding.weight.detach().clone()
+        zq, res = m(z)
+        dy = W.normal(seed, "dy", zshape)
+        ((zq * dy).sum() + res["quantizer_loss"]).backward()
+        out["vq_" + name] = {"seed": seed, "kwargs": dict(kw), "zshape": list(zshape), "shapes": shapes,
+                             "zq": summarize(zq), "indices": res["min_encoding_indices"].clone(),
+                             "quantizer_loss": float(res["quantizer_loss"]), "commitment_loss": float(res["commitment_loss"]),
+                             "codebook_loss": float(res["codebook_loss"]), "dz": summarize(z.grad), "dcodebook": summarize(m.embedding.weight.grad)}
+        if kw.get("clustering_vq"):
+            out["vq_" + name]["codebook_after"] = summarize(m.embedding.weight.detach())
+            out["vq_" + name]["embed_prob_after"] = m.embed_prob.detach().clone()
+            out["vq_" + name]["codebook_moved"] = rel_l2(m.embedding.weight.detach(), code0)
+    save("blocks_tokenizers.pt", out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -336,6 +417,7 @@ def main():
     gen_train_steps_fixture(TV, RU)
     gen_tokenizer_fixtures()
     gen_blocks_fixture()
+    gen_block_tokenizer_fixture()
 
 
 if __name__ == "__main__":

@@ -300,6 +300,102 @@ def uvit_block(x, sd, n_heads, skip=None, lowp=False):
 
 
 # --------------------------------------------------------------------------------------
+# blocks.py tokenizer wrappers (blocks.py:209, 286, 365, 406)
+# --------------------------------------------------------------------------------------
+def _sub(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def conv3x3_same(x, w, b):
+    """nn.Conv2d(Cin, Cout, 3, padding=1) as nine shifted channel mixes (reference blocks.py:333)."""
+    B, C, H, W = x.shape
+    xp = torch.zeros((B, C, H + 2, W + 2), dtype=x.dtype)
+    xp[:, :, 1:H + 1, 1:W + 1] = x
+    y = b.view(1, -1, 1, 1).expand(B, -1, H, W)
+    for kh in range(3):
+        for kw in range(3):
+            y = y + torch.einsum("oi,bihw->bohw", w[:, :, kh, kw], xp[:, :, kh:kh + H, kw:kw + W])
+    return y
+
+
+def _blocks_stack(x, sd, n_layers, n_heads, lowp):
+    """`for i: x = self.transformer[i](x)` between the two LND permutes (blocks.py:270-273); run batch-first."""
+    x = x.transpose(0, 1)
+    for i in range(n_layers):
+        x = residual_attention_block(x, _sub(sd, f"transformer.{i}."), n_heads, lowp)
+    return x.transpose(0, 1)
+
+
+def titok_block_encoder(pixels, latent_tokens, sd, patch, grid, n_layers, n_heads, lowp=False):
+    """Reference blocks.TiTokEncoder.forward (blocks.py:256-282) -> [B, token_size, 1, n_latents]."""
+    B = pixels.shape[0]
+    w = sd["patch_embed.weight"]
+    x = linear(patchify(pixels, patch), w.reshape(w.shape[0], -1), sd["patch_embed.bias"], lowp).float()
+    x = torch.cat([sd["class_embedding"].unsqueeze(0).expand(B, -1, -1), x], dim=1) + sd["positional_embedding"]
+    lat = (latent_tokens + sd["latent_token_positional_embedding"]).unsqueeze(0).expand(B, -1, -1)
+    x = torch.cat([x, lat], dim=1)
+    x = layer_norm_affine(x, sd["ln_pre.weight"], sd["ln_pre.bias"])
+    x = _blocks_stack(x, sd, n_layers, n_heads, lowp)
+    lat = layer_norm_affine(x[:, 1 + grid * grid:], sd["ln_post.weight"], sd["ln_post.bias"])
+    cw = sd["conv_out.weight"]
+    z = linear(lat, cw.reshape(cw.shape[0], -1), sd["conv_out.bias"], lowp).float()      # 1x1 conv over the width axis
+    return z.permute(0, 2, 1).reshape(B, cw.shape[0], 1, lat.shape[1])
+
+
+def titok_block_decoder(z_quantized, sd, patch, grid, n_layers, n_heads, text_guidance=None, lowp=False):
+    """Reference blocks.TiTokDecoder.forward (blocks.py:335-356); with `text_guidance` [B, T, E] it is
+    blocks.TATiTokDecoder.forward (blocks.py:369-403)."""
+    B, C, H, Wl = z_quantized.shape
+    x = z_quantized.reshape(B, C * H, Wl).permute(0, 2, 1)
+    x = linear(x, sd["decoder_embed.weight"], sd["decoder_embed.bias"], lowp).float()
+    mask = sd["mask_token"].expand(B, grid * grid, -1)
+    mask = torch.cat([sd["class_embedding"].unsqueeze(0).expand(B, -1, -1), mask], dim=1) + sd["positional_embedding"]
+    x = torch.cat([mask, x + sd["latent_token_positional_embedding"][:Wl]], dim=1)
+    if text_guidance is not None:
+        t = linear(text_guidance, sd["text_guidance_proj.weight"], sd["text_guidance_proj.bias"], lowp).float()
+        x = torch.cat([x, t + sd["text_guidance_positional_embedding"]], dim=1)
+    x = layer_norm_affine(x, sd["ln_pre.weight"], sd["ln_pre.bias"])
+    x = _blocks_stack(x, sd, n_layers, n_heads, lowp)
+    x = layer_norm_affine(x[:, 1:1 + grid * grid], sd["ln_post.weight"], sd["ln_post.bias"])
+    fw = sd["ffn.0.weight"]
+    y = linear(x, fw.reshape(fw.shape[0], -1), sd["ffn.0.bias"], lowp).float()
+    return conv3x3_same(pixel_shuffle(y, grid, patch), sd["conv_out.weight"], sd["conv_out.bias"])
+
+
+def vector_quantizer(z, codebook, commitment_cost=0.25, use_l2_norm=False):
+    """Reference blocks.VectorQuantizer.forward (blocks.py:430-495) without the clustering update:
+    -> (z_quantized [b,c,h,w] straight-through, quantizer_loss, commitment_loss, codebook_loss, indices [b,h,w])."""
+    zc = z.float().permute(0, 2, 3, 1)
+    zf = zc.reshape(-1, zc.shape[-1])
+    unit = (lambda t: t / t.norm(dim=-1, keepdim=True).clamp_min(1e-12)) if use_l2_norm else (lambda t: t)
+    zn, en = unit(zf), unit(codebook)
+    d = zn.pow(2).sum(1, keepdim=True) + en.pow(2).sum(1) - 2 * zn @ en.t()
+    idx = d.detach().argmin(dim=1)
+    zq = unit(codebook[idx]).view(zc.shape)
+    zc = unit(zc)
+    commitment = commitment_cost * (zq.detach() - zc).pow(2).mean()
+    cb_loss = (zq - zc.detach()).pow(2).mean()
+    out = (zc + (zq - zc).detach()).permute(0, 3, 1, 2)
+    return out, commitment + cb_loss, commitment, cb_loss, idx.view(zc.shape[:3])
+
+
+def vq_cluster_update(z, codebook, embed_prob, decay=0.99, use_l2_norm=False):
+    """The `clustering_vq` training-time codebook refresh of blocks.py:454-479 for ONE process (gather = identity):
+    -> (new codebook, new embed_prob)."""
+    zc = z.float().permute(0, 2, 3, 1)
+    zf = zc.reshape(-1, zc.shape[-1])
+    unit = (lambda t: t / t.norm(dim=-1, keepdim=True).clamp_min(1e-12)) if use_l2_norm else (lambda t: t)
+    zn, en = unit(zf), unit(codebook)
+    d = zn.pow(2).sum(1, keepdim=True) + en.pow(2).sum(1) - 2 * zn @ en.t()
+    K = codebook.shape[0]
+    probs = torch.bincount(d.argmin(dim=1), minlength=K).float() / zf.shape[0]
+    embed_prob = embed_prob * decay + probs * (1 - decay)
+    feat = zf[d.argmin(dim=0)]
+    w = torch.exp(-(embed_prob * K * 10) / (1 - decay) - 1e-3).unsqueeze(1)
+    return codebook * (1 - w) + feat * w, embed_prob
+
+
+# --------------------------------------------------------------------------------------
 # LR schedule (reference utils.py:5-9), closed form
 # --------------------------------------------------------------------------------------
 def lr_at(step: int, base_lr: float, warmup_steps: int, train_steps: int, min_lr: float) -> float:

@@ -333,3 +333,97 @@ def test_blocks_surface_vs_reference_golden(hip, name):
     lo = blocks_oracle_run(name, case, lowp=True)
     assert O.rel_l2(y.detach().cpu(), lo["y"]) < 5e-3
     assert O.rel_l2(x.grad.cpu(), lo["dx"]) < 1.2e-2
+
+
+# ------------------------------------------------------------------ blocks.py tokenizer wrappers
+@pytest.mark.parametrize("name,cls", [("encoder", "TiTokEncoder"), ("decoder", "TiTokDecoder"), ("tatitok_decoder", "TATiTokDecoder")])
+def test_block_tokenizers_vs_reference_golden(hip, name, cls):
+    import blocks as BK
+    from test_host import _tok_cfg
+    from test_oracle import block_tokenizer_inputs, block_tokenizer_oracle_run
+    g = load_golden("blocks_tokenizers.pt")
+    cfg, B, case = g["config"], g["batch"], g[name]
+    m = getattr(BK, cls)(_tok_cfg(cfg))
+    m.load_state_dict(W.module_state(case["seed"], case["shapes"]), strict=True)
+    m = m.cuda()
+    ins = [t.cuda().requires_grad_(True) for t in block_tokenizer_inputs(name, case, cfg, B)]
+    y = m(*ins)
+    assert list(y.shape) == case["y"]["shape"]
+    dy = W.normal(case["seed"], "dy", tuple(y.shape)).cuda()
+    (y * dy).sum().backward()
+    torch.cuda.synchronize()
+    floor = case["ref_bf16_floor"]
+    # against the reference's fp32 result, judged by the reference's own bf16-autocast deviation
+    assert _err(y.detach(), case["y"]) < 2 * floor["y"] + 2e-3
+    for t, ref, fl in zip(ins, case["dinputs"], floor["dinputs"]):
+        assert _err(t.grad, ref) < 2 * fl + 5e-3
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert _err(p.grad, case["grads"][k]) < 2 * floor["grads_max"] + 6e-3, k
+    lo_y, lo_dins, lo_grads = block_tokenizer_oracle_run(name, case, cfg, B, lowp=True)
+    # tighter: against the oracle's bf16-flow emulation (8 layers deep: rounding-order differences accumulate)
+    assert O.rel_l2(y.detach().cpu(), lo_y) < 1e-2
+    for t, ref in zip(ins, lo_dins):
+        assert O.rel_l2(t.grad.cpu(), ref) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["vq_plain", "vq_l2norm", "vq_wide", "vq_cluster"])
+def test_vector_quantizer_vs_reference_golden(hip, name):
+    import blocks as BK
+    from test_oracle import vq_case_tensors
+    case = load_golden("blocks_tokenizers.pt")[name]
+    code, z, dy = vq_case_tensors(case)
+    vq = BK.VectorQuantizer(**case["kwargs"])
+    vq.load_state_dict({"embedding.weight": code}, strict=False)
+    vq = vq.cuda().train()
+    z = z.cuda().requires_grad_(True)
+    zq, res = vq(z)
+    ((zq * dy.cuda()).sum() + res["quantizer_loss"]).backward()
+    torch.cuda.synchronize()
+    # fp32 arithmetic: indices bit-exact with the reference, values to fp32 rounding
+    assert torch.equal(res["min_encoding_indices"].cpu(), case["indices"])
+    assert abs(float(res["quantizer_loss"]) - case["quantizer_loss"]) < 1e-6
+    assert abs(float(res["commitment_loss"]) - case["commitment_loss"]) < 1e-7 and abs(float(res["codebook_loss"]) - case["codebook_loss"]) < 1e-7
+    assert _err(zq.detach(), case["zq"]) < 1e-6 and _err(z.grad, case["dz"]) < 1e-5
+    assert _err(vq.embedding.weight.grad, case["dcodebook"]) < 1e-5
+    if case["kwargs"].get("clustering_vq"):
+        assert _err(vq.embedding.weight.detach(), case["codebook_after"]) < 1e-6
+        assert torch.allclose(vq.embed_prob.cpu(), case["embed_prob_after"], atol=1e-7)
+
+
+def test_conv3x3_kernel_vs_oracle(hip):
+    """The decoders' 3x3 conv_out (reference blocks.py:333): fp32 kernel against the oracle's shifted-sum restatement,
+    forward, input gradient, weight and bias gradient; odd sizes exercise the zero padding and the grid-stride tails."""
+    from vitamd import ops
+    for (B, H, Wd) in ((2, 5, 7), (3, 64, 48), (1, 256, 256)):
+        x = W.normal(5, f"x{H}", (B, 3, H, Wd)); w = W.normal(5, "w", (3, 3, 3, 3), 0.3); b = W.normal(5, "b", (3,))
+        dy = W.normal(5, f"dy{H}", (B, 3, H, Wd))
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = O.conv3x3_same(xr, wr, br)
+        gx, gw, gb = torch.autograd.grad((yr * dy).sum(), [xr, wr, br])
+        y = ops.conv3x3_fwd(x.cuda(), w.cuda(), b.cuda())
+        dx, dw, db = ops.conv3x3_bwd(x.cuda(), w.cuda(), dy.cuda())
+        torch.cuda.synchronize()
+        assert O.rel_l2(y.cpu(), yr.detach()) < 1e-6
+        assert O.rel_l2(dx.cpu(), gx) < 1e-6
+        assert O.rel_l2(dw.cpu(), gw) < 2e-5 and O.rel_l2(db.cpu(), gb) < 2e-5
+    from vitamd.lib import VitamdError
+    with pytest.raises(VitamdError):
+        ops.conv3x3_fwd(torch.zeros(1, 4, 8, 8, device="cuda"), torch.zeros(3, 4, 3, 3, device="cuda"), None)
+
+
+def test_vq_nearest_wide_codes(hip):
+    """d > 64 path of the nearest-code kernel against a float64 brute force (first-minimum tie-break; duplicates planted)."""
+    from vitamd import ops
+    for (M, K, d) in ((37, 300, 65), (513, 1024, 256), (9, 70, 1024)):
+        x = W.normal(9, f"x{d}", (M, d)); e = W.normal(9, f"e{d}", (K, d))
+        e[K // 2] = e[3]                                    # exact duplicate: the lower index must win
+        x[0] = e[3]
+        idx = ops.vq_nearest(x.cuda(), e.cuda()).cpu()
+        d2 = (x.double().unsqueeze(1) - e.double().unsqueeze(0)).pow(2).sum(-1)
+        ref = d2.argmin(dim=1)
+        assert idx[0] == 3
+        bad = (idx != ref).nonzero().flatten()
+        for m in bad.tolist():                              # fp32-vs-fp64 near ties only
+            assert abs(float(d2[m, idx[m]] - d2[m, ref[m]])) < 1e-4 * float(d2[m, ref[m]])
+        assert len(bad) <= max(1, M // 100)

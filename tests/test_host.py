@@ -130,3 +130,31 @@ def test_blocks_surface_state_dict_contract():
         BK.UViTBlock(128, 2, drop_path=0.1)
     with pytest.raises(NotImplementedError):
         BK.Attention(96, 2)            # head_dim 48
+
+
+def _tok_cfg(c):
+    from types import SimpleNamespace as NS
+    return NS(image_size=c["image_size"], patch_size=c["patch_size"], transformer=c["transformer"], latent_tokens=c["latent_tokens"],
+              latent_dim=c["latent_dim"], model=NS(vq_model={"text_context_length": c["text_context_length"], "text_embed_dim": c["text_embed_dim"]}))
+
+
+def test_blocks_tokenizer_wrappers_state_dict_contract():
+    """blocks.py:209,286,365,406 - same class names, ctor signatures and checkpoint keys/shapes as the reference
+    (shapes recorded from the reference's own state_dict in tests/golden/blocks_tokenizers.pt)."""
+    import blocks as BK
+    g = load_golden("blocks_tokenizers.pt")
+    cfg = _tok_cfg(g["config"])
+    for name, cls in (("encoder", "TiTokEncoder"), ("decoder", "TiTokDecoder"), ("tatitok_decoder", "TATiTokDecoder")):
+        m = getattr(BK, cls)(cfg)
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == g[name]["shapes"], name
+    for name in ("vq_plain", "vq_l2norm", "vq_wide", "vq_cluster"):
+        vq = BK.VectorQuantizer(**g[name]["kwargs"])
+        shapes = {k: list(v.shape) for k, v in vq.state_dict().items() if k != "embed_prob"}
+        assert shapes == g[name]["shapes"], name
+        assert float(vq.embedding.weight.abs().max()) <= 1.0 / vq.codebook_size + 1e-9       # reference init (blocks.py:421)
+    assert "embed_prob" in BK.VectorQuantizer(clustering_vq=True).state_dict()
+    # no CPU path: the wrappers raise instead of silently computing on the host
+    from vitamd.lib import VitamdError
+    enc = BK.TiTokEncoder(cfg)
+    with pytest.raises((VitamdError, RuntimeError)):
+        enc(torch.zeros(1, 3, 32, 32), torch.zeros(8, 512))

@@ -186,3 +186,71 @@ def test_blocks_oracle_matches_reference():
             assert O.rel_l2(got["dskip"], case["dskip"]) < 1e-5, name
         for k, ref in case["grads"].items():
             assert O.rel_l2(got["grads"][k], ref) < 2e-5, (name, k)
+
+
+# ---------------------------------------------------------------- blocks.py tokenizer wrappers
+def block_tokenizer_inputs(name, case, cfg, B):
+    s, lat, ldim = case["seed"], cfg["latent_tokens"], cfg["latent_dim"]
+    if name == "encoder":
+        return [W.normal(s, "pixels", (B, 3, cfg["image_size"], cfg["image_size"])), W.normal(s, "latent_tokens", (lat, 512), 0.05)]
+    ins = [W.normal(s, "zq", (B, ldim, 1, lat))]
+    if name == "tatitok_decoder":
+        ins.append(W.normal(s, "text", (B, cfg["text_context_length"], cfg["text_embed_dim"])))
+    return ins
+
+
+def block_tokenizer_oracle_run(name, case, cfg, B, lowp=False):
+    sd = W.module_state(case["seed"], case["shapes"])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ins = [t.requires_grad_(True) for t in block_tokenizer_inputs(name, case, cfg, B)]
+    patch, grid = cfg["patch_size"], cfg["image_size"] // cfg["patch_size"]
+    if name == "encoder":
+        y = O.titok_block_encoder(ins[0], ins[1], leaves, patch, grid, 8, 8, lowp)
+    else:
+        y = O.titok_block_decoder(ins[0], leaves, patch, grid, 8, 8, text_guidance=ins[1] if len(ins) > 1 else None, lowp=lowp)
+    dy = W.normal(case["seed"], "dy", tuple(y.shape))
+    names = list(leaves)
+    grads = torch.autograd.grad((y.float() * dy).sum(), ins + [leaves[k] for k in names])
+    return y.detach(), list(grads[:len(ins)]), dict(zip(names, grads[len(ins):]))
+
+
+def test_block_tokenizers_oracle_matches_reference():
+    g = load_golden("blocks_tokenizers.pt")
+    cfg, B = g["config"], g["batch"]
+    for name in ("encoder", "decoder", "tatitok_decoder"):
+        case = g[name]
+        y, dins, grads = block_tokenizer_oracle_run(name, case, cfg, B)
+        assert list(y.shape) == case["y"]["shape"]
+        assert _err(y, case["y"]) < 1e-5, name
+        for got, ref in zip(dins, case["dinputs"]):
+            assert _err(got, ref) < 3e-5, name
+        assert set(grads) == set(case["grads"])
+        for k, ref in case["grads"].items():
+            assert _err(grads[k], ref) < 5e-5, (name, k)
+
+
+def vq_case_tensors(case):
+    sd = W.module_state(case["seed"], case["shapes"])
+    z = W.normal(case["seed"], "z", tuple(case["zshape"])) * 0.05
+    dy = W.normal(case["seed"], "dy", tuple(case["zshape"]))
+    return sd["embedding.weight"], z, dy
+
+
+def test_vector_quantizer_oracle_matches_reference():
+    g = load_golden("blocks_tokenizers.pt")
+    for name in ("vq_plain", "vq_l2norm", "vq_wide", "vq_cluster"):
+        case = g[name]
+        code, z, dy = vq_case_tensors(case)
+        code, z = code.clone().requires_grad_(True), z.requires_grad_(True)
+        l2 = bool(case["kwargs"].get("use_l2_norm", False))
+        zq, loss, commit, cbl, idx = O.vector_quantizer(z, code, 0.25, l2)
+        assert torch.equal(idx, case["indices"]), name
+        assert abs(float(loss) - case["quantizer_loss"]) < 1e-6 * max(1.0, abs(case["quantizer_loss"])), name
+        assert abs(float(commit) - case["commitment_loss"]) < 1e-7 and abs(float(cbl) - case["codebook_loss"]) < 1e-7
+        dz, dcode = torch.autograd.grad((zq * dy).sum() + loss, [z, code])
+        assert _err(zq.detach(), case["zq"]) < 1e-6 and _err(dz, case["dz"]) < 1e-5 and _err(dcode, case["dcodebook"]) < 1e-5, name
+        if case["kwargs"].get("clustering_vq"):
+            new_code, prob = O.vq_cluster_update(z.detach(), code.detach(), torch.zeros(code.shape[0]), 0.99, l2)
+            assert case["codebook_moved"] > 0.1            # the refresh really changed the codebook in the reference run
+            assert _err(new_code, case["codebook_after"]) < 1e-6
+            assert torch.allclose(prob, case["embed_prob_after"], atol=1e-7)

@@ -8,17 +8,26 @@ GELU / residual epilogues).
 
 Differences from the reference, stated: head_dim must be 64; the SDPA runs in bf16 (blocks.Attention
 upcasts q,k,v to fp32 first, blocks.py:100); the nn.Dropout / DropPath layers only accept rate 0 on this
-path (blocks.Attention's 'flash' mode ignores attn_drop anyway, blocks.py:98-103).  The tokenizer
-wrappers of blocks.py:208-505 (TiTokEncoder/TiTokDecoder/TATiTokDecoder/VectorQuantizer, used only by
-the out-of-scope train_tatitok.py; they need a 3x3 convolution and an OmegaConf config tree) are not
-provided — the transformer.py-based TiTok lives in train_titok.py."""
+path (blocks.Attention's 'flash' mode ignores attn_drop anyway, blocks.py:98-103).
+
+The tokenizer wrappers of blocks.py:208-505 (TiTokEncoder / TiTokDecoder / TATiTokDecoder / VectorQuantizer)
+are here as well, over the same kernels: patch-embed GEMM with fused bias + positional embedding, fp32 affine
+LayerNorm kernel for ln_pre / ln_post, BlockFn per layer (batch-major, so the reference's two LND permutes per
+model disappear), padded-Linear GEMMs for the 1x1 convolutions / decoder_embed / text projection, the
+3x3 `conv_out` kernel and the nearest-code search kernel.  Token concatenation, slicing, the pixel-shuffle
+rearrange and the O(tokens x token_size) elementwise terms of the quantiser losses are torch device ops.
+`config` is duck-typed (attribute access, plus `.model.vq_model.get(...)` for TATiTokDecoder) - no OmegaConf."""
 from collections import OrderedDict
+
+from typing import Mapping, Text, Tuple
 
 import torch
 import torch.nn as nn
+from einops.layers.torch import Rearrange
 
-from vitamd.block_functions import AttnProjFn, BlockFn, MlpFn
-from vitamd.functions import linear
+from vitamd import ops
+from vitamd.block_functions import AttnProjFn, BlockFn, Conv3x3Fn, LayerNormAffineFn, MlpFn
+from vitamd.functions import PatchEmbedFn, linear
 
 ATTENTION_MODE = "hip"   # the reference picks 'flash' / 'xformers' / 'math' at import (blocks.py:72-81)
 print(f"attention mode is {ATTENTION_MODE}")
@@ -68,15 +77,18 @@ class ResidualAttentionBlock(nn.Module):
         return y.transpose(0, 1)
 
     def forward(self, x: torch.Tensor):
+        return self.forward_nld(x.transpose(0, 1).contiguous()).transpose(0, 1)   # LND -> NLD: one row per token, batch-major
+
+    def forward_nld(self, xt: torch.Tensor):
+        """Same block on batch-first [N, L, D] input (what the kernels want; used by the tokenizer wrappers below)."""
         has_mlp = self.mlp_ratio > 0
-        xt = x.transpose(0, 1).contiguous()                       # LND -> NLD: one row per token, batch-major
         y = BlockFn.apply(xt, self.ln_1.weight, self.ln_1.bias, self.attn.in_proj_weight, self.attn.in_proj_bias,
                           self.attn.out_proj.weight, self.attn.out_proj.bias,
                           self.ln_2.weight if has_mlp else None, self.ln_2.bias if has_mlp else None,
                           self.mlp.c_fc.weight if has_mlp else None, self.mlp.c_fc.bias if has_mlp else None,
                           self.mlp.c_proj.weight if has_mlp else None, self.mlp.c_proj.bias if has_mlp else None,
                           self.n_head, has_mlp)
-        return y.transpose(0, 1)
+        return y
 
 
 class Attention(nn.Module):
@@ -160,3 +172,233 @@ class UViTBlock(nn.Module):
                              self.attn.proj.weight, self.attn.proj.bias, self.norm2.weight, self.norm2.bias,
                              self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,
                              self.attn.num_heads, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# tokenizer wrappers (reference blocks.py:204-505)
+# ------------------------------------------------------------------------------------------------
+_WIDTH = {"small": 512, "base": 768, "large": 1024}
+_LAYERS = {"small": 8, "base": 12, "large": 24}
+_HEADS = {"small": 8, "base": 12, "large": 16}
+
+
+def _expand_token(token, batch_size: int):
+    return token.unsqueeze(0).expand(batch_size, -1, -1)
+
+
+def _ln(mod, x):
+    return LayerNormAffineFn.apply(x.contiguous(), mod.weight, mod.bias, mod.eps)
+
+
+def _conv1x1_tokens(conv, tokens):
+    """nn.Conv2d(kernel_size=1) parameters applied to token-major [B, T, C] input -> [B, T, out]."""
+    return linear(tokens, conv.weight.view(conv.weight.shape[0], -1), conv.bias)
+
+
+class TiTokEncoder(nn.Module):
+    """Image patches + class token + learned latent tokens through `num_layers` ResidualAttentionBlocks; the
+    latent tokens' outputs are projected to `token_size` (reference blocks.py:208-282).  Parameter names as there."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.image_size = config.image_size
+        self.patch_size = config.patch_size
+        self.grid_size = self.image_size // self.patch_size
+        self.model_size = config.transformer
+        self.num_latent_tokens = config.latent_tokens
+        self.token_size = config.latent_dim
+        self.width = _WIDTH[self.model_size]
+        self.num_layers = _LAYERS[self.model_size]
+        self.num_heads = _HEADS[self.model_size]
+
+        self.patch_embed = nn.Conv2d(in_channels=3, out_channels=self.width, kernel_size=self.patch_size, stride=self.patch_size, bias=True)
+        scale = self.width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(1, self.width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn(self.grid_size ** 2 + 1, self.width))
+        self.latent_token_positional_embedding = nn.Parameter(scale * torch.randn(self.num_latent_tokens, self.width))
+        self.ln_pre = nn.LayerNorm(self.width)
+        self.transformer = nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.transformer.append(ResidualAttentionBlock(self.width, self.num_heads, mlp_ratio=4.0))
+        self.ln_post = nn.LayerNorm(self.width)
+        self.conv_out = nn.Conv2d(self.width, self.token_size, kernel_size=1, bias=True)
+
+    def forward(self, pixel_values, latent_tokens):
+        batch_size = pixel_values.shape[0]
+        g2 = self.grid_size ** 2
+        pos = self.positional_embedding
+        # conv patchify + bias + positional embedding in one GEMM; the class token (+ its position) is row 0
+        x = PatchEmbedFn.apply(pixel_values, self.patch_embed.weight, self.patch_embed.bias, pos[1:], self.class_embedding + pos[:1],
+                               self.patch_size, g2)                                   # [B, 1 + grid**2, width] fp32
+        latent_tokens = _expand_token(latent_tokens.to(x.dtype) + self.latent_token_positional_embedding, batch_size)
+        x = torch.cat([x, latent_tokens], dim=1)
+        x = _ln(self.ln_pre, x)
+        for blk in self.transformer:
+            x = blk.forward_nld(x)
+        latent_tokens = _ln(self.ln_post, x[:, 1 + g2:])
+        z = _conv1x1_tokens(self.conv_out, latent_tokens)                            # [B, latents, token_size]
+        return z.permute(0, 2, 1).reshape(batch_size, self.token_size, 1, self.num_latent_tokens)
+
+
+class TiTokDecoder(nn.Module):
+    """Quantised latent tokens + one mask token per image patch -> pixels (reference blocks.py:285-356)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.image_size = config.image_size
+        self.patch_size = config.patch_size
+        self.grid_size = self.image_size // self.patch_size
+        self.model_size = config.transformer
+        self.num_latent_tokens = config.latent_tokens
+        self.token_size = config.latent_dim
+        self.width = _WIDTH[self.model_size]
+        self.num_layers = _LAYERS[self.model_size]
+        self.num_heads = _HEADS[self.model_size]
+
+        self.decoder_embed = nn.Linear(self.token_size, self.width, bias=True)
+        scale = self.width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(1, self.width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn(self.grid_size ** 2 + 1, self.width))
+        self.mask_token = nn.Parameter(scale * torch.randn(1, 1, self.width))
+        self.latent_token_positional_embedding = nn.Parameter(scale * torch.randn(self.num_latent_tokens, self.width))
+        self.ln_pre = nn.LayerNorm(self.width)
+        self.transformer = nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.transformer.append(ResidualAttentionBlock(self.width, self.num_heads, mlp_ratio=4.0))
+        self.ln_post = nn.LayerNorm(self.width)
+        # parameter containers with the reference's names (ffn.0.*, conv_out.*); applied through the kernels below
+        self.ffn = nn.Sequential(
+            nn.Conv2d(self.width, self.patch_size * self.patch_size * 3, 1, padding=0, bias=True),
+            Rearrange('b (p1 p2 c) h w -> b c (h p1) (w p2)', p1=self.patch_size, p2=self.patch_size),)
+        self.conv_out = nn.Conv2d(3, 3, 3, padding=1, bias=True)
+
+    def _tokens(self, z_quantized):
+        N, C, H, W = z_quantized.shape
+        assert H == 1 and W == self.num_latent_tokens, f"{H}, {W}, {self.num_latent_tokens}"
+        x = z_quantized.reshape(N, C * H, W).permute(0, 2, 1)  # NLD
+        x = linear(x, self.decoder_embed.weight, self.decoder_embed.bias)
+        seq_len = x.shape[1]
+        mask_tokens = self.mask_token.repeat(N, self.grid_size ** 2, 1).to(x.dtype)
+        mask_tokens = torch.cat([_expand_token(self.class_embedding, N).to(mask_tokens.dtype), mask_tokens], dim=1)
+        mask_tokens = mask_tokens + self.positional_embedding.to(mask_tokens.dtype)
+        x = x + self.latent_token_positional_embedding[:seq_len]
+        return torch.cat([mask_tokens, x], dim=1)
+
+    def _pixels(self, x):
+        batchsize, g, p = x.shape[0], self.grid_size, self.patch_size
+        x = _ln(self.ln_pre, x)
+        for blk in self.transformer:
+            x = blk.forward_nld(x)
+        x = _ln(self.ln_post, x[:, 1:1 + g * g])                                   # remove cls embed
+        y = _conv1x1_tokens(self.ffn[0], x)                                         # [B, grid**2, p*p*3], token t = (h, w)
+        img = y.view(batchsize, g, g, p, p, 3).permute(0, 5, 1, 3, 2, 4).reshape(batchsize, 3, g * p, g * p)
+        return Conv3x3Fn.apply(img, self.conv_out.weight, self.conv_out.bias)
+
+    def forward(self, z_quantized):
+        return self._pixels(self._tokens(z_quantized))
+
+
+class TATiTokDecoder(TiTokDecoder):
+    """TiTokDecoder with projected text-guidance tokens appended to the sequence (reference blocks.py:359-403)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        scale = self.width ** -0.5
+        self.text_context_length = config.model.vq_model.get("text_context_length", 77)
+        self.text_embed_dim = config.model.vq_model.get("text_embed_dim", 768)
+        self.text_guidance_proj = nn.Linear(self.text_embed_dim, self.width)
+        self.text_guidance_positional_embedding = nn.Parameter(scale * torch.randn(self.text_context_length, self.width))
+
+    def forward(self, z_quantized, text_guidance):
+        x = self._tokens(z_quantized)
+        text_guidance = linear(text_guidance, self.text_guidance_proj.weight, self.text_guidance_proj.bias)
+        text_guidance = text_guidance + self.text_guidance_positional_embedding
+        return self._pixels(torch.cat([x, text_guidance], dim=1))
+
+
+def gather(t):
+    """All-gather along dim 0 across data-parallel ranks (identity in a single process).  The reference calls
+    a `gather` it never defines or imports (blocks.py:457,466,467 - a NameError as written); this is the
+    accelerate-style meaning the surrounding comments describe."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t.contiguous())
+    return torch.cat(parts, dim=0)
+
+
+class VectorQuantizer(torch.nn.Module):
+    """Nearest-code quantiser with commitment / codebook losses and straight-through gradients, fp32
+    (reference blocks.py:405-505).  The argmin over the codebook runs on the nearest-code kernel."""
+
+    def __init__(self, codebook_size: int = 1024, token_size: int = 256, commitment_cost: float = 0.25,
+                 use_l2_norm: bool = False, clustering_vq: bool = False):
+        super().__init__()
+        self.codebook_size = codebook_size
+        self.token_size = token_size
+        self.commitment_cost = commitment_cost
+        self.embedding = torch.nn.Embedding(codebook_size, token_size)
+        self.embedding.weight.data.uniform_(-1.0 / codebook_size, 1.0 / codebook_size)
+        self.use_l2_norm = use_l2_norm
+        self.clustering_vq = clustering_vq
+        if clustering_vq:
+            self.decay = 0.99
+            self.register_buffer("embed_prob", torch.zeros(self.codebook_size))
+
+    def forward(self, z: torch.Tensor) -> Tuple[torch.Tensor, Mapping[Text, torch.Tensor]]:
+        z = z.float().permute(0, 2, 3, 1).contiguous()                 # b c h w -> b h w c
+        z_flattened = z.reshape(-1, z.shape[-1])
+        unnormed_z_flattened = z_flattened
+        if self.use_l2_norm:
+            z_flattened = torch.nn.functional.normalize(z_flattened, dim=-1)
+            embedding = torch.nn.functional.normalize(self.embedding.weight, dim=-1)
+        else:
+            embedding = self.embedding.weight
+        zq, eq = z_flattened.detach().contiguous(), embedding.detach().float().contiguous()
+        min_encoding_indices = ops.vq_nearest(zq, eq)                  # argmin_k ||z - e_k||^2  (blocks.py:442-446)
+        z_quantized = self.get_codebook_entry(min_encoding_indices).view(z.shape)
+        if self.use_l2_norm:
+            z = torch.nn.functional.normalize(z, dim=-1)
+
+        commitment_loss = self.commitment_cost * torch.mean((z_quantized.detach() - z) ** 2)
+        codebook_loss = torch.mean((z_quantized - z.detach()) ** 2)
+
+        if self.clustering_vq and self.training:
+            with torch.no_grad():
+                encoding_indices = gather(min_encoding_indices)
+                if len(min_encoding_indices.shape) != 1:
+                    raise ValueError(f"min_encoding_indices in a wrong shape, {min_encoding_indices.shape}")
+                # usage of each codebook entry
+                avg_probs = torch.bincount(encoding_indices, minlength=self.codebook_size).float() / encoding_indices.shape[0]
+                self.embed_prob.mul_(self.decay).add_(avg_probs, alpha=1 - self.decay)
+                # closest sampling: for every code the nearest (gathered) sample - the same kernel with the roles swapped
+                all_z = gather(zq)
+                all_unnormed_z_flattened = gather(unnormed_z_flattened).detach()
+                indices = ops.vq_nearest(eq, all_z)
+                random_feat = all_unnormed_z_flattened[indices]
+                decay = torch.exp(-(self.embed_prob * self.codebook_size * 10) / (1 - self.decay) - 1e-3).unsqueeze(1).repeat(1, self.token_size)
+                self.embedding.weight.data = self.embedding.weight.data * (1 - decay) + random_feat * decay
+
+        loss = commitment_loss + codebook_loss
+        z_quantized = z + (z_quantized - z).detach()                   # preserve gradients
+        z_quantized = z_quantized.permute(0, 3, 1, 2).contiguous()     # b h w c -> b c h w
+        result_dict = dict(
+            quantizer_loss=loss,
+            commitment_loss=commitment_loss,
+            codebook_loss=codebook_loss,
+            min_encoding_indices=min_encoding_indices.view(z_quantized.shape[0], z_quantized.shape[2], z_quantized.shape[3]))
+        return z_quantized, result_dict
+
+    def get_codebook_entry(self, indices):
+        if len(indices.shape) == 1:
+            z_quantized = self.embedding(indices)
+        elif len(indices.shape) == 2:
+            z_quantized = torch.einsum('bd,dn->bn', indices, self.embedding.weight)
+        else:
+            raise NotImplementedError
+        if self.use_l2_norm:
+            z_quantized = torch.nn.functional.normalize(z_quantized, dim=-1)
+        return z_quantized

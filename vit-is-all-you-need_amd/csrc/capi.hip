@@ -3,7 +3,7 @@
 #include "vitamd_internal.h"
 #include "../../include/vitamd.h"
 
-extern "C" int vitamd_abi_version(void) { return 3; }
+extern "C" int vitamd_abi_version(void) { return 4; }
 
 int g_vitamd_debug = 0;
 // timing-only ablation knob for tools/ablate_*.py (bit 0: skip GELU math, bit 1: skip the second store,

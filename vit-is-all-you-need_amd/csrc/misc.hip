@@ -226,11 +226,71 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
   if (m < M) idx[m] = besti;
 }
 
+// Wide codes (64 < d <= 1024, e.g. the reference blocks.VectorQuantizer default token_size 256, blocks.py:408):
+// a block owns 8 rows (staged in LDS); every thread walks the codes k = tid, tid+256, ... computing the 8
+// distances of its code in one pass over the code's floats (the codebook is a few MB and stays in L2), then
+// the block reduces (distance, index) per row with the same first-minimum tie-break as the narrow kernel.
+__global__ __launch_bounds__(256) void vq_nearest_wide_kernel(const float* __restrict__ x, const float* __restrict__ e,
+                                                              long long* __restrict__ idx, int M, int K, int d) {
+  constexpr int RB = 8;
+  extern __shared__ float xs[];            // [RB][d]
+  __shared__ float rbest[4][RB];
+  __shared__ int ribest[4][RB];
+  const int m0 = blockIdx.x * RB;
+  for (int i = threadIdx.x; i < RB * d; i += 256) {
+    const int r = i / d;
+    xs[i] = (m0 + r < M) ? x[(size_t)(m0 + r) * d + (i - r * d)] : 0.f;
+  }
+  __syncthreads();
+  float best[RB];
+  int besti[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) { best[r] = 3.0e38f; besti[r] = 0x7fffffff; }
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float* ek = e + (size_t)k * d;
+    float s[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) s[r] = 0.f;
+    for (int c = 0; c < d; ++c) {
+      const float ev = ek[c];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) { const float t = xs[r * d + c] - ev; s[r] += t * t; }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) if (s[r] < best[r]) { best[r] = s[r]; besti[r] = k; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    float b = best[r]; int bi = besti[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(b, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ob < b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+    }
+    if (lane == 0) { rbest[wave][r] = b; ribest[wave][r] = bi; }
+  }
+  __syncthreads();
+  if (threadIdx.x < RB && m0 + threadIdx.x < M) {
+    float b = rbest[0][threadIdx.x]; int bi = ribest[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) {
+      const float ob = rbest[w][threadIdx.x]; const int oi = ribest[w][threadIdx.x];
+      if (ob < b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+    }
+    idx[m0 + threadIdx.x] = bi;
+  }
+}
+
 }  // namespace
 
 extern "C" int vitamd_vq_nearest(const float* x, const float* codebook, long long* idx, int M, int K, int d, void* stream) {
-  if (M <= 0 || K <= 0 || d <= 0 || d > 64) return VITAMD_ERR_SHAPE;
+  if (M <= 0 || K <= 0 || d <= 0 || d > 1024) return VITAMD_ERR_SHAPE;
   if (!x || !codebook || !idx) return VITAMD_ERR_ARG;
+  if (d > 64) {
+    hipLaunchKernelGGL(vq_nearest_wide_kernel, dim3((M + 7) / 8), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, x, codebook, idx, M, K, d);
+    return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+  }
   const int grid = (M + 255) / 256;
   if (d <= 16) hipLaunchKernelGGL(vq_nearest_kernel<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, codebook, idx, M, K, d);
   else hipLaunchKernelGGL(vq_nearest_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, codebook, idx, M, K, d);

@@ -164,3 +164,44 @@ class MlpFn(torch.autograd.Function):
         ops.gemm_tn(dpre, xb, dW1, accumulate=False)
         dx = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)
         return dx.view(*lead, K).to(xdtype), dW1, db1, dW2, db2
+
+
+class LayerNormAffineFn(torch.autograd.Function):
+    """Stand-alone nn.LayerNorm (weight + bias) in fp32: the tokenizers' ln_pre / ln_post (reference blocks.py:247,253,
+    320,326), whose input and output both live in the fp32 token stream."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        D = x.shape[-1]
+        x2 = _f32c(x).reshape(-1, D)
+        y, mean, rstd = ops.layernorm_affine_fwd_f32(x2, _f32c(gamma), _f32c(beta), eps)
+        ctx.save_for_backward(x2, mean, rstd, gamma)
+        ctx.meta = (tuple(x.shape), x.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        shape, xdtype = ctx.meta
+        D = shape[-1]
+        dg, db = _zeros(D, g.device), _zeros(D, g.device)
+        dx = ops.layernorm_affine_bwd_f32(_f32c(g).reshape(-1, D), x2, mean, rstd, _f32c(gamma), dg, db)
+        return dx.view(shape).to(xdtype), dg, db, None
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """nn.Conv2d(3, 3, 3, padding=1) on NCHW fp32 images (reference blocks.py:333 `conv_out`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xf, wf = _f32c(x), _f32c(w)
+        y = ops.conv3x3_fwd(xf, wf, _f32c(b) if b is not None else None)
+        ctx.save_for_backward(xf, wf)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xf, wf = ctx.saved_tensors
+        dx, dw, db = ops.conv3x3_bwd(xf, wf, _f32c(g), need_dx=ctx.needs_input_grad[0], need_dw=True, has_bias=ctx.has_bias)
+        return dx, dw, db

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitamd.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c = ctypes
 _P, _I, _F, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_ulonglong
@@ -28,6 +28,8 @@ SIGNATURES = {
     "vitamd_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vitamd_layernorm_affine_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "vitamd_layernorm_affine_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vitamd_layernorm_affine_fwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "vitamd_layernorm_affine_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],
@@ -40,6 +42,8 @@ SIGNATURES = {
     "vitamd_colsum_bf16": [_P, _P, _I, _I, _I, _P],
     "vitamd_embed_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vitamd_vq_nearest": [_P, _P, _P, _I, _I, _I, _P],
+    "vitamd_conv3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vitamd_conv3x3_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vitamd_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
 }
 

@@ -150,6 +150,29 @@ def layernorm_affine_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, g_res=None, wa
     return g, gb
 
 
+def layernorm_affine_fwd_f32(x, gamma, beta, eps=LN_EPS):
+    """x fp32 [M,D] -> (y fp32 = LN(x)*gamma+beta, mean, rstd): the LayerNorm whose output is not a GEMM operand."""
+    _need(x, F32, "x", 2); _need(gamma, F32, "gamma", 1); _need(beta, F32, "beta", 1)
+    M, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((M,), dtype=F32, device=x.device)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    _lib.check(_L().vitamd_layernorm_affine_fwd_f32(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, float(eps), _stream()),
+               "layernorm_affine_fwd_f32")
+    return y, mean, rstd
+
+
+def layernorm_affine_bwd_f32(dy, x, mean, rstd, gamma, dgamma, dbeta):
+    """dy fp32 -> dx fp32; dgamma / dbeta (fp32 [D]) are accumulated into."""
+    _need(dy, F32, "dy", 2); _need(x, F32, "x", 2); _need(gamma, F32, "gamma", 1)
+    _need(dgamma, F32, "dgamma", 1); _need(dbeta, F32, "dbeta", 1)
+    M, D = x.shape
+    g = torch.empty_like(x)
+    _lib.check(_L().vitamd_layernorm_affine_bwd_f32(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(g), _p(dgamma), _p(dbeta), M, D,
+                                                    _stream()), "layernorm_affine_bwd_f32")
+    return g
+
+
 # ------------------------------------------------------------------------------------------ attention
 def attention_fwd(qkv, B, N, H, causal=False, dropout=(0.0, 0)):
     """qkv bf16 [B*N, 3*H*64] (packed (qkv, head, dh)) -> o bf16 [B*N, H*64], lse2 fp32 [B,H,N].
@@ -257,3 +280,29 @@ def vq_nearest(x, codebook):
     idx = torch.empty((M,), dtype=torch.int64, device=x.device)
     _lib.check(_L().vitamd_vq_nearest(_p(x), _p(codebook), _p(idx), M, K, d, _stream()), "vq_nearest")
     return idx
+
+
+def conv3x3_fwd(x, w, bias):
+    """x fp32 [B,3,H,W], w fp32 [3,3,3,3], bias fp32 [3] or None -> y fp32 [B,3,H,W] (stride 1, zero padding 1)."""
+    _need(x, F32, "x", 4); _need(w, F32, "w", 4)
+    B, C, H, W = x.shape
+    Co = w.shape[0]
+    if tuple(w.shape) != (Co, C, 3, 3):
+        raise _lib.VitamdError("conv3x3: weight must be [Cout, Cin, 3, 3]")
+    y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+    _lib.check(_L().vitamd_conv3x3_fwd(_p(x), _p(w), _p(bias), _p(y), B, C, Co, H, W, _stream()), f"conv3x3_fwd[Cin={C},Cout={Co}]")
+    return y
+
+
+def conv3x3_bwd(x, w, dy, need_dx=True, need_dw=True, has_bias=True):
+    """-> (dx or None, dw or None, db or None), all fp32."""
+    _need(x, F32, "x", 4); _need(w, F32, "w", 4); _need(dy, F32, "dy", 4)
+    B, C, H, W = x.shape
+    Co = w.shape[0]
+    if tuple(dy.shape) != (B, Co, H, W):
+        raise _lib.VitamdError("conv3x3_bwd: dy shape mismatch")
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.zeros_like(w) if need_dw else None
+    db = torch.zeros((Co,), dtype=F32, device=x.device) if (need_dw and has_bias) else None
+    _lib.check(_L().vitamd_conv3x3_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), B, C, Co, H, W, _stream()), "conv3x3_bwd")
+    return dx, dw, db
