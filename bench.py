@@ -48,9 +48,9 @@ def kernel_roofline(dev):
     cs = torch.zeros(4 * D, device=dev)
     calls = [
         ("qkv", lambda: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3), 2.0 * M * D * 3 * D),
-        ("fc1+gelu", lambda: ops.gemm_nt(x1, w1, ops.EPI_GELU, bias=b4), 2.0 * M * D * 4 * D),
+        ("fc1+gelu", lambda: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4), 2.0 * M * D * 4 * D),
         ("fc2+resid", lambda: ops.gemm_nt(x4, w2, ops.EPI_RESID_F32, bias=b1, aux=res), 2.0 * M * D * 4 * D),
-        ("dgrad_fc2", lambda: ops.gemm_nt(x1, w2_t, ops.EPI_DGELU, aux=x4, colsum=cs), 2.0 * M * D * 4 * D),
+        ("dgrad_fc2", lambda: ops.gemm_nt(x1, w2_t, ops.EPI_DMUL, aux=x4, colsum=cs), 2.0 * M * D * 4 * D),
         ("dgrad_fc1", lambda: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 4 * D),
         ("dgrad_qkv", lambda: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 3 * D),
     ]

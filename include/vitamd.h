@@ -37,6 +37,9 @@ int vitamd_abi_version(void);
 #define VITAMD_EPI_DGELU 3     /* out bf16 = bf16(acc) * gelu'(aux_bf16); colsum += column sums   (backward of transformer.py:38-39) */
 #define VITAMD_EPI_PATCH_F32 4 /* out f32[b*seq+extra+p] = bf16(acc+bias) + aux_f32[p]  replaces train_vit.py:39-41 (Conv2d patchify + rearrange + pos_emb) */
 #define VITAMD_EPI_F32 5       /* out f32 = acc */
+#define VITAMD_EPI_GELU_DG 6   /* as GELU, but out bf16 = gelu'(pre-activation): the derivative is evaluated here, where its exp is
+                                  shared with the erf and the VALU work hides under the output stores */
+#define VITAMD_EPI_DMUL 7      /* as DGELU, but aux_bf16 already holds gelu'(pre) (written by GELU_DG): out = bf16(bf16(acc) * aux) */
 
 /* Requirements: K % 64 == 0, N % 4 == 0, ldo % 4 == 0.  bias may be NULL.  `tile` 0 = auto.
  * Forward of nn.Linear (x W^T + b): A = x, B = W.  Input gradient (dy W): A = dy, B = W^T. */

@@ -105,9 +105,28 @@ def linear(x, w, b, lowp=False):
     return _r(y, lowp)
 
 
+class _GeluStoredGradBF16(torch.autograd.Function):
+    """lowp emulation of the MI355X flow: the forward keeps bf16(gelu'(x)) (the derivative is evaluated in the fc1
+    epilogue, rounded once to bf16 for storage), the backward multiplies the bf16 upstream gradient by it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        cdf = 0.5 * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+        pdf = torch.exp(-0.5 * x * x) * (1.0 / math.sqrt(2.0 * math.pi))
+        ctx.save_for_backward((cdf + x * pdf).to(torch.bfloat16).to(torch.float32))
+        return (x * cdf).to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dg,) = ctx.saved_tensors
+        return g.to(torch.bfloat16).to(torch.float32) * dg
+
+
 def gelu_erf(x, lowp=False):
     """Exact (erf) GELU; reference transformer.py:38 `nn.GELU()` (approximate='none')."""
-    return _r(0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0)))), lowp)
+    if lowp:
+        return _GeluStoredGradBF16.apply(x)
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
 def split_qkv(qkv: torch.Tensor, n_heads: int):

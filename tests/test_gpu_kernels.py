@@ -56,7 +56,7 @@ def test_gemm_nt_epilogues(hip, tile):
 
     class ops:  # same API with the tile selector pinned
         gemm_nt = staticmethod(functools.partial(_ops.gemm_nt, tile=tile))
-        EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32 = range(6)
+        EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32, EPI_GELU_DG, EPI_DMUL = range(8)
     M, N, K = 333, 512, 256
     a, b = r16(randn((M, K), 3)), r16(randn((N, K), 4, 0.1))
     bias = randn((N,), 5)
@@ -82,6 +82,18 @@ def test_gemm_nt_epilogues(hip, tile):
     O.gelu_erf(x).backward(r16(acc))
     assert O.rel_l2(y, r16(x.grad)) < 3e-3
     assert O.rel_l2(cs.cpu(), y.sum(0)) < 1e-4
+    # stored-derivative pair: GELU_DG writes gelu'(pre) (bf16) beside gelu(pre); DMUL multiplies by it as stored
+    dgl, act2 = ops.gemm_nt(ad, bd, ops.EPI_GELU_DG, bias=biasd)
+    assert torch.equal(act2, act)
+    xp = ref.clone().requires_grad_(True)
+    O.gelu_erf(xp).backward(torch.ones_like(ref))
+    assert O.rel_l2(dgl.float().cpu(), r16(xp.grad)) < 2e-3
+    assert float((dgl.float().cpu() - xp.grad).abs().max()) < 6e-3          # bf16 rounding of values up to 1.13
+    cs2 = torch.zeros(N, device=dev())
+    dg_in = r16(randn((M, N), 17, 0.5))
+    y2 = ops.gemm_nt(ad, bd, ops.EPI_DMUL, aux=dg_in.to(dev(), BF16), colsum=cs2).float().cpu()
+    assert O.rel_l2(y2, r16(r16(acc) * dg_in)) < 2e-3
+    assert O.rel_l2(cs2.cpu(), y2.sum(0)) < 1e-4
     # patch epilogue: row remap + pos add
     n_p, extra = 9, 2
     Bn = 37

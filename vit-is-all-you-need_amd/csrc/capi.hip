@@ -13,7 +13,11 @@ extern "C" int vitamd_set_debug(int bits) { g_vitamd_debug = bits; return 0; }
 extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
                                    float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
                                    int tile, void* stream) {
-  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug, 0u, 1.0f, 0u, 0u, 0};
+  // ABI codes 6 / 7 are the GELU / dGELU epilogues in stored-derivative form (out = gelu'(pre) ; multiply by aux as stored)
+  const int dg = (epi == 6 || epi == 7) ? 1 : 0;
+  if (epi == 6) epi = EPI_GELU;
+  if (epi == 7) epi = EPI_DGELU;
+  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug, 0u, 1.0f, 0u, 0u, 0, dg};
   if (!(tile >= 0 && tile <= 6) && tile != 128 && tile != 256 && (tile < 21 || tile > 24)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }
@@ -42,7 +46,7 @@ static bool dropout_params(float p, unsigned& thresh, float& scale) {
 extern "C" int vitamd_linear_dropout_resid_bf16(const void* A, const void* B, float* out, const float* bias, const float* resid,
                                                 int M, int N, int K, float dropout_p, unsigned long long seed, void* stream) {
   GemmNtArgs p{A, B, out, nullptr, bias, resid, nullptr, M, N, K, N, EPI_RESID_F32, 0, 0, 0, 0, g_vitamd_debug, 0u, 1.0f,
-               (unsigned)seed, (unsigned)(seed >> 32), 0};
+               (unsigned)seed, (unsigned)(seed >> 32), 0, 0};
   if (!dropout_params(dropout_p, p.drop_thresh, p.drop_scale)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }

@@ -57,6 +57,17 @@ __device__ __forceinline__ float fast_erf(float x) {
   return __builtin_copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_fwd(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// gelu(x) and gelu'(x) together: the exp(-x^2/2) inside the erf approximation IS the Gaussian of the derivative,
+// so the pair costs one v_exp + one v_rcp (the derivative rides along for ~4 more VALU ops).
+__device__ __forceinline__ float gelu_fwd_grad(float x, float& dg) {
+  const float ax = __builtin_fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float pl = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-ax * ax);                        // exp(-x^2 / 2)
+  const float cdf = 0.5f * (1.0f + __builtin_copysignf(1.0f - pl * e, x));
+  dg = cdf + x * (0.39894228040143268f * e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad(float x) {
   // d/dx [x Phi(x)] = Phi(x) + x phi(x)
   float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));

@@ -68,7 +68,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pre[r] = round_bf16(v[r]);
-          act[r] = (p.dbg & 1) ? pre[r] : gelu_fwd(pre[r]);
+          float dg;
+          act[r] = (p.dbg & 1) ? pre[r] : gelu_fwd_grad(pre[r], dg);
+          if (p.gelu_dg) pre[r] = dg;                       // `out` carries gelu'(pre) for the backward
         }
         u32x2 o1 = {pack_bf16x2(pre[0], pre[1]), pack_bf16x2(pre[2], pre[3])};
         u32x2 o2 = {pack_bf16x2(act[0], act[1]), pack_bf16x2(act[2], act[3])};
@@ -90,7 +92,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          o[r] = round_bf16(round_bf16(v[r]) * gelu_grad(pre[r]));
+          o[r] = round_bf16(round_bf16(v[r]) * (p.gelu_dg ? pre[r] : gelu_grad(pre[r])));
           cs[j][r] += o[r];
         }
         u32x2 ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
@@ -233,15 +235,20 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
     const int rloc = rsub + 8 * it;
     const int m = mbase + 8 * it;
     const u32x4 v = *(const u32x4*)(tile + rloc * 128 + pc * 16);
-    const bool ok = m < p.M && ncol_ok;
+    const bool ok = m < p.M && ncol_ok && !(p.dbg & 0x10000);   // dbg bit 16: timing-only, no output stores
     if constexpr (EPI == EPI_BIAS_BF16) {
       if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
     } else if constexpr (EPI == EPI_GELU) {
       u32x4 a;
+      u32x4 d = v;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a[c] = pack_bf16x2(gelu_fwd(bf16lo(v[c])), gelu_fwd(bf16hi(v[c])));
+      for (int c = 0; c < 4; ++c) {
+        float dlo, dhi;
+        a[c] = pack_bf16x2(gelu_fwd_grad(bf16lo(v[c]), dlo), gelu_fwd_grad(bf16hi(v[c]), dhi));
+        if (p.gelu_dg) d[c] = pack_bf16x2(dlo, dhi);       // `out` carries gelu'(pre) for the backward
+      }
       if (ok) {
-        ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
+        ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), d);
         ST16((u32x4*)((__bf16*)p.out2 + (size_t)m * ldo + n), a);
       }
     } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) {
@@ -271,8 +278,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
       u32x4 o;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float lo = round_bf16(bf16lo(v[c]) * gelu_grad(bf16lo(pz[c])));
-        const float hi = round_bf16(bf16hi(v[c]) * gelu_grad(bf16hi(pz[c])));
+        const bool raw = p.gelu_dg;         // aux already holds gelu'(pre)
+        const float lo = round_bf16(bf16lo(v[c]) * (raw ? bf16lo(pz[c]) : gelu_grad(bf16lo(pz[c]))));
+        const float hi = round_bf16(bf16hi(v[c]) * (raw ? bf16hi(pz[c]) : gelu_grad(bf16hi(pz[c]))));
         if (ok) { cs[2 * c] += lo; cs[2 * c + 1] += hi; }
         o[c] = pack_bf16x2(lo, hi);
       }
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
   const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7)) & 7) << 4);
   const int a_off = wm * WTM * 128 + frag_off;
   const int b_off = BM * 128 + wn * WTN * 128 + frag_off;
-  const int nkt = K / 64;
+  const int nkt = (p.dbg & 0x20000) ? 1 : K / 64;   // dbg bit 17: timing-only, one K-tile (epilogue cost in isolation)
 
   // Phase stagger: the odd workgroups of the FIRST round start ~8 us late, so that from then on the
   // two halves of the chip reach their HBM-bound epilogues at different times (successor workgroups
@@ -567,8 +575,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
   {
     const int req = (p.dbg >> 8) & 0xff;
     const int st = req == 255 ? 0 : (req ? req : 8);
-    if (st && gridDim.x > 256 && blockIdx.x < 256 && (blockIdx.x & 1)) {
-      for (int i = 0; i < st; ++i) __builtin_amdgcn_s_sleep(32);
+    int P = (p.dbg >> 20) & 0xf;                       // number of phases (timing knob; default 2)
+    if (P == 0) P = 2;
+    if (st && gridDim.x > 256 && blockIdx.x < 256) {
+      const int ph = (p.dbg & (1 << 24)) ? ((blockIdx.x >> 3) % P) : (blockIdx.x % P);
+      for (int i = 0; i < st * ph; ++i) __builtin_amdgcn_s_sleep(32);
     }
   }
   {  // prologue: whole tile 0
@@ -825,10 +836,15 @@ __device__ __forceinline__ void epilogue_rows_halves(const GemmNtArgs& p, f32x4 
         if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
       } else if constexpr (EPI == EPI_GELU) {
         u32x4 a;
+        u32x4 d = v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[c] = pack_bf16x2(gelu_fwd(bf16lo(v[c])), gelu_fwd(bf16hi(v[c])));
+        for (int c = 0; c < 4; ++c) {
+          float dlo, dhi;
+          a[c] = pack_bf16x2(gelu_fwd_grad(bf16lo(v[c]), dlo), gelu_fwd_grad(bf16hi(v[c]), dhi));
+          if (p.gelu_dg) d[c] = pack_bf16x2(dlo, dhi);     // `out` carries gelu'(pre) for the backward
+        }
         if (ok) {
-          ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
+          ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), d);
           ST16((u32x4*)((__bf16*)p.out2 + (size_t)m * ldo + n), a);
         }
       } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) {
@@ -858,8 +874,8 @@ __device__ __forceinline__ void epilogue_rows_halves(const GemmNtArgs& p, f32x4 
         u32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float lo = round_bf16(bf16lo(v[c]) * gelu_grad(bf16lo(pz[c])));
-          const float hi = round_bf16(bf16hi(v[c]) * gelu_grad(bf16hi(pz[c])));
+          const float lo = round_bf16(bf16lo(v[c]) * (p.gelu_dg ? bf16lo(pz[c]) : gelu_grad(bf16lo(pz[c]))));
+          const float hi = round_bf16(bf16hi(v[c]) * (p.gelu_dg ? bf16hi(pz[c]) : gelu_grad(bf16hi(pz[c]))));
           if (ok) { cs[2 * c] += lo; cs[2 * c + 1] += hi; }
           o[c] = pack_bf16x2(lo, hi);
         }

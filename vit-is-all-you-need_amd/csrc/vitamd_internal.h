@@ -29,6 +29,9 @@ struct GemmNtArgs {
   float drop_scale;           // 1 / (1 - p)
   unsigned drop_seed_lo, drop_seed_hi;
   int row0;                   // global row of this launch's row 0 (tail split): dropout indices stay global
+  // stored-derivative GELU (ABI codes VITAMD_EPI_GELU_DG / VITAMD_EPI_DMUL): EPI_GELU writes out = bf16(gelu'(pre)) instead
+  // of pre, EPI_DGELU multiplies by aux as stored instead of evaluating gelu'(aux)
+  int gelu_dg;
 };
 
 struct GemmTnArgs {

@@ -37,7 +37,7 @@ class BlockFn(torch.autograd.Function):
             w1_b, _ = WEIGHTS.get(w1, True)
             w2_b, _ = WEIGHTS.get(w2, True)
             bln, mean2, rstd2 = ops.layernorm_affine_fwd(x1, _f32c(g2), _f32c(be2))
-            pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU, bias=_f32c(b1))
+            pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU_DG, bias=_f32c(b1))
             out = ops.gemm_nt(h, w2_b, ops.EPI_RESID_F32, bias=_f32c(b2), aux=x1)
             saved += [mean2, rstd2, bln, pre, h]
         ctx.save_for_backward(*saved)
@@ -64,7 +64,7 @@ class BlockFn(torch.autograd.Function):
             dW2 = torch.empty((D, Dh), dtype=F32, device=dev)
             ops.gemm_tn(dy2, h, dW2, accumulate=False)
             db1 = _zeros(Dh, dev)
-            dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)
+            dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DMUL, aux=pre, colsum=db1)
             dW1 = torch.empty((Dh, D), dtype=F32, device=dev)
             ops.gemm_tn(dpre, bln, dW1, accumulate=False)
             dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)
@@ -138,7 +138,7 @@ class MlpFn(torch.autograd.Function):
         xb = ops.cast_bf16(_f32c(x).reshape(-1, K))
         w1_b, _ = WEIGHTS.get(w1, True)
         w2_b, _ = WEIGHTS.get(w2, True)
-        pre, h = ops.gemm_nt(xb, w1_b, ops.EPI_GELU, bias=_f32c(b1))
+        pre, h = ops.gemm_nt(xb, w1_b, ops.EPI_GELU_DG, bias=_f32c(b1))
         y = ops.gemm_nt(h, w2_b, ops.EPI_BIAS_BF16, bias=_f32c(b2))
         ctx.save_for_backward(xb, pre, h)
         ctx.params = (w1, w2)
@@ -159,7 +159,7 @@ class MlpFn(torch.autograd.Function):
         dW2 = torch.empty((Dout, Dh), dtype=F32, device=dev)
         ops.gemm_tn(dy, h, dW2, accumulate=False)
         db1 = _zeros(Dh, dev)
-        dpre = ops.gemm_nt(dy, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)
+        dpre = ops.gemm_nt(dy, w2_t, ops.EPI_DMUL, aux=pre, colsum=db1)
         dW1 = torch.empty((Dh, K), dtype=F32, device=dev)
         ops.gemm_tn(dpre, xb, dW1, accumulate=False)
         dx = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)

@@ -103,6 +103,9 @@ class WeightCache:
 WEIGHTS = WeightCache()
 
 
+GELU_STORED_GRAD = True   # A/B knob (tools/ab_gelu.py); False = keep the pre-activation and evaluate gelu' in the backward
+
+
 def _f32c(t):
     return t.detach().to(F32).contiguous()
 
@@ -127,7 +130,9 @@ def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad, p_
     qkv = ops.gemm_nt(a, wqkv_b, ops.EPI_BIAS_BF16, bias=bqkv)                   # fused QKV      transformer.py:27
     o, lse = ops.attention_fwd(qkv, B, N, H, causal, dropout=drop[:2])           # SDPA           transformer.py:28-29
     x1, bln, mean2, rstd2 = ops.layernorm_fwd(x0, addend=o)                      # residual + LN2 transformer.py:43-44
-    pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU, bias=b1)                       # fc1 + GELU     transformer.py:37-38
+    # fc1 + GELU (transformer.py:37-38); `pre` holds bf16(gelu'(fc1 out)) for the backward - the derivative is evaluated
+    # here, where its exp is shared with the erf and the VALU work hides under the output stores (-85 us per layer in dgrad fc2)
+    pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU_DG if GELU_STORED_GRAD else ops.EPI_GELU, bias=b1)
     if p_mlp > 0:
         x2 = ops.linear_dropout_resid(h, w2_b, b2, x1, drop[2:])                 # fc2 + dropout + residual
     else:
@@ -226,7 +231,7 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
         if not have_db2:
             ops.colsum(dy2, db2)
     on_side(wgrad_fc2, dy2, h, dW2, db2)
-    dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DGELU, aux=pre, colsum=db1)            # dgrad fc2 . gelu'
+    dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DMUL if GELU_STORED_GRAD else ops.EPI_DGELU, aux=pre, colsum=db1)   # dgrad fc2 . gelu'
     on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False), dpre, bln, dW1)
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True)

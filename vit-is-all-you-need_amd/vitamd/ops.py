@@ -9,7 +9,7 @@ import torch
 
 from . import lib as _lib
 
-EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32 = range(6)
+EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32, EPI_GELU_DG, EPI_DMUL = range(8)
 LN_EPS = 1e-5
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -41,7 +41,7 @@ def _need(t, dtype, name, ndim=None):
 # ------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(a, b, epi, *, bias=None, aux=None, out=None, out2=None, colsum=None, n_patches=0, seq=0, extra=0,
             out_rows=None, tile=0):
-    """out = epilogue(a[M,K] @ b[N,K]^T).  Returns out (and out2 for EPI_GELU)."""
+    """out = epilogue(a[M,K] @ b[N,K]^T).  Returns out (and out2 for EPI_GELU / EPI_GELU_DG)."""
     _need(a, BF16, "a", 2); _need(b, BF16, "b", 2)
     M, K = a.shape
     N, K2 = b.shape
@@ -51,14 +51,14 @@ def gemm_nt(a, b, epi, *, bias=None, aux=None, out=None, out2=None, colsum=None,
     if out is None:
         out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
     _need(out, out_dtype, "out")
-    if epi == EPI_GELU and out2 is None:
+    if epi in (EPI_GELU, EPI_GELU_DG) and out2 is None:
         out2 = torch.empty((M, N), dtype=BF16, device=a.device)
     if bias is not None:
         _need(bias, F32, "bias", 1)
     code = _L().vitamd_gemm_nt_bf16(_p(a), _p(b), _p(out), _p(out2), _p(bias), _p(aux), _p(colsum), M, N, K, N, epi,
                                     n_patches, seq, extra, tile, _stream())
     _lib.check(code, f"gemm_nt[M={M},N={N},K={K},epi={epi}]")
-    return (out, out2) if epi == EPI_GELU else out
+    return (out, out2) if epi in (EPI_GELU, EPI_GELU_DG) else out
 
 
 _WORKSPACES = {}
