@@ -42,6 +42,10 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 __device__ __forceinline__ void buf_glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsigned voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
+// same addressing, but into registers (the conventional global -> VGPR -> ds_write staging path)
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
 }

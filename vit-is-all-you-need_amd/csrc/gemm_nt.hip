@@ -598,6 +598,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
     const int soff = (kt + 1) * 128;
 
     bf16x8 bq[2][NT], aq[2][2];
+    u32x4 stg[ABL == 5 ? PPW : 1];    // ABL 5: stage the next tile through VGPRs + ds_write instead of LDS-DMA (correct results)
 #pragma unroll
     for (int j = 0; j < NT; ++j) if (ABL != 3 || kt == 0) bq[0][j] = *(const bf16x8*)(buf + b_off + j * 2048);
 #pragma unroll
@@ -605,7 +606,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const int ks = g >> 2, pr = g & 3;
-      if (more && ABL != 2) buf_glds16(g < 4 ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
+      if (more && ABL != 2) {
+        if constexpr (ABL == 5) stg[g] = buf_load16(g < 4 ? rsrcA : rsrcB, voff[g], soff);
+        else buf_glds16(g < 4 ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
+      }
       if (g < 7) {
         const int ks2 = (g + 1) >> 2, pr2 = (g + 1) & 3;
 #pragma unroll
@@ -624,6 +628,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
           else acc[2 * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[g & 1][i], acc[2 * pr + i][j], 0, 0, 0);
       if constexpr (ABL == 4) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (ABL == 5) {
+      if (more) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) *(u32x4*)(nbase + g * NW * 1024 + lane * 16) = stg[g];
+      }
     }
   }
   if constexpr (EPI == EPI_F32) gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
@@ -1068,7 +1078,10 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
     else tile = (p.K % 64 == 0) ? 128 : 1;
   }
   if (tile == 1) return ring_ok ? launch_ring<256, 128, 2, 2, EPI>(p, stream) : VITAMD_ERR_SHAPE;
-  if (tile == 2) return (ring_ok && p.K % 64 == 0) ? launch_pipe<EPI>(p, stream) : VITAMD_ERR_SHAPE;
+  if (tile == 2) {
+    if (!(ring_ok && p.K % 64 == 0)) return VITAMD_ERR_SHAPE;
+    return (p.dbg & 0x20000000) ? launch_pipe<EPI, 5>(p, stream) : launch_pipe<EPI>(p, stream);   // dbg bit 29: A/B of the staging path
+  }
   if constexpr (EPI != EPI_F32) {
     if (tile == 6) return (ring_ok && p.K % 64 == 0 && p.N % 8 == 0 && p.ldo % 8 == 0) ? launch_persist<EPI>(p, stream) : VITAMD_ERR_SHAPE;
   }

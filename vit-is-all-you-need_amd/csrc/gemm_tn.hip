@@ -3,9 +3,13 @@
 //   reference transformer.py:21,37,39 and of the patch-embed conv train_vit.py:34).
 //
 // Both operands are stored with the REDUCTION index as the slow (row) dimension, so neither is
-// MFMA-fragment shaped in memory.  gfx950 answer: stage [64 r][256 cols] tiles row-major by LDS-DMA
-// (buffer_load ... lds, whole 512-B rows, zero-fill past the last row through the buffer descriptor's
-// range check) and read the fragments with the hardware transpose read ds_read_b64_tr_b16.  The 16-B
+// MFMA-fragment shaped in memory.  gfx950 answer: stage [64 r][256 cols] tiles row-major (whole 512-B
+// rows, zero-fill past the last row through the buffer descriptor's range check) and read the fragments
+// with the hardware transpose read ds_read_b64_tr_b16.  Staging is buffer_load -> VGPR -> ds_write_b128
+// (issued group by group under the MFMAs of the current stage, written at its end); the LDS-DMA form
+// (buffer_load ... lds, same addresses, same LDS image) is kept behind dbg bits 26-28 = 5: ablations show this
+// kernel is bound by operand delivery (removing every MFMA: 310 -> 296 us) and the register path
+// delivers ~6 % faster here, while the NT kernel prefers LDS-DMA (tools/ablate_tn.py, tools/ab_dbg.py).  The 16-B
 // chunk index of row r is XOR-ed with (r&3)<<2 (on the global source side) which makes every
 // transposed read bank-conflict-free (tools/lds_banks.py).  mfma_f32_32x32x16_bf16 so one accumulator
 // register of a wave = two 128-B row segments: the shape float atomics run at full rate with.
@@ -33,7 +37,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool WS>
+template <bool WS, int ABL = 0>   // ABL: timing-only ablations (1 = no MFMA, 2 = no LDS-DMA, 3 = no transposed reads: results are garbage); 4 = stage through VGPRs + ds_write instead of LDS-DMA (correct results)
 __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -111,17 +115,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(const GemmTnArgs a, in
     // four 16-deep groups of 8 MFMAs; each first issues two DMA pieces of the next stage and the
     // transposed reads of the NEXT group's fragments (register double buffer), then its MFMAs
     bf16x8 af[2][MT], bfr[2][NT];
+    u32x4 stg[ABL == 4 ? PPW : 1];
+    if (ABL != 3 || s == s_lo) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bfr[0][j] = tr_frag(buf + offB[j]);
+      for (int j = 0; j < NT; ++j) bfr[0][j] = tr_frag(buf + offB[j]);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[0][i] = tr_frag(buf + offA[i]);
+      for (int i = 0; i < MT; ++i) af[0][i] = tr_frag(buf + offA[i]);
+    }
 #pragma unroll
     for (int ks = 0; ks < BR / 16; ++ks) {
-      if (more) {
-        buf_glds16(rsrc, nbase + (2 * ks) * 1024, voff[2 * ks], soff);
-        buf_glds16(rsrc, nbase + (2 * ks + 1) * 1024, voff[2 * ks + 1], soff);
+      if (more && ABL != 2) {
+        if constexpr (ABL == 4) {
+          stg[2 * ks] = buf_load16(rsrc, voff[2 * ks], soff);
+          stg[2 * ks + 1] = buf_load16(rsrc, voff[2 * ks + 1], soff);
+        } else {
+          buf_glds16(rsrc, nbase + (2 * ks) * 1024, voff[2 * ks], soff);
+          buf_glds16(rsrc, nbase + (2 * ks + 1) * 1024, voff[2 * ks + 1], soff);
+        }
       }
-      if (ks + 1 < BR / 16) {
+      if (ks + 1 < BR / 16 && (ABL != 3 || s == s_lo)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) bfr[(ks + 1) & 1][j] = tr_frag(buf + offB[j] + (ks + 1) * 16 * 512);
 #pragma unroll
@@ -131,8 +143,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(const GemmTnArgs a, in
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+          if constexpr (ABL == 1) { asm volatile("" ::"v"(af[ks & 1][i]), "v"(bfr[ks & 1][j])); }
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (ABL == 4) {
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) *(u32x4*)(nbase + i * 1024 + lane * 16) = stg[i];
+      }
     }
   }
 
@@ -348,7 +367,19 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   const bool k16 = (g_vitamd_debug & 64) != 0;   // A/B knob: bit 6 selects the 16x16x32 variant (measured 1.6x SLOWER: kept for study)
   if (use_ws) {
     if (k16) hipLaunchKernelGGL(gemm_tn16_kernel<true>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
-    else hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
+    else {
+      // staging path: global -> VGPR -> ds_write (default: whole-step A/B -0.6..-0.8 ms against LDS-DMA for THIS kernel, while
+      // the NT kernel is 1.1 ms slower with it; tools/ab_dbg.py).  dbg bits 26-28: 5 = LDS-DMA form, 1-3 = timing-only ablations
+      const int sel = (g_vitamd_debug >> 26) & 7;
+      auto kern = sel == 1 ? gemm_tn_kernel<true, 1> : sel == 2 ? gemm_tn_kernel<true, 2> : sel == 3 ? gemm_tn_kernel<true, 3>
+                : sel == 5 ? gemm_tn_kernel<true, 0> : gemm_tn_kernel<true, 4>;
+      static bool attr_sel[8] = {};
+      if (!attr_sel[sel]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return VITAMD_ERR_LAUNCH;
+        attr_sel[sel] = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
+    }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q,
                        ntile, splits, a.accumulate);
   } else {
