@@ -78,16 +78,16 @@ def kernel_roofline(dev):
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/c_final_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same
+    (profiles/r01/e_final_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same
     bench command, 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction), averaged over the six NT GEMM
     launches of a layer (3 plain + gelu + residual + dgelu).  None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "c_final_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01", "e_final_pmc_hbm_traffic.json")
     try:
         prof = json.load(open(path))
         per = {k: v["hbm_MB_avg_corrected(2*fetch+write)"] for k, v in prof.items() if "gemm_nt_pipe_kernel<" in k}
         mb = (3 * per[[k for k in per if "<0, 0>" in k][0]] + sum(per[[k for k in per if f"<{e}, 0>" in k][0]] for e in (1, 2, 3))) / 6
         return {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int((3 * 339 + 702 + 625 + 702) / 6 * 1e6),
-                "source": "profiles/r01/c_final_pmc_hbm_traffic.json"}
+                "source": "profiles/r01/e_final_pmc_hbm_traffic.json"}
     except Exception:
         return None
 
