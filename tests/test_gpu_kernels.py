@@ -137,6 +137,34 @@ def test_gemm_tn_exact_integers(hip, R, P, Q, splits):
     assert torch.equal(out.cpu(), l.t() @ r)
 
 
+@pytest.mark.parametrize("R,P,Q", [(4096, 256, 384), (5000, 512, 768), (8197, 768, 768), (4100, 256, 1152)])
+def test_gemm_tn_wide_tile_exact_integers(hip, R, P, Q):
+    """The opt-in 256x384-tile kernel (vitamd_set_debug bit 25; P % 256 == 0, Q % 384 == 0, R >= 4096, auto splits): integer
+    data, so the fp32 result is exact whatever the split / summation order; ragged R exercises the zero-filled last stage."""
+    import ctypes
+    from vitamd import ops, lib
+    L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+    L.vitamd_set_debug(1 << 25)
+    try:
+        _tn_wide_case(ops, R, P, Q)
+    finally:
+        L.vitamd_set_debug(0)
+
+
+def _tn_wide_case(ops, R, P, Q):
+    l = ints((R, P), -2, 2, 31)
+    r = ints((R, Q), -3, 3, 32)
+    init = ints((P, Q), -5, 5, 33)
+    ref = l.t() @ r
+    ld, rd = l.to(dev(), BF16), r.to(dev(), BF16)
+    out = torch.full((P, Q), 123.0, device=dev())
+    ops.gemm_tn(ld, rd, out, accumulate=False)
+    assert torch.equal(out.cpu(), ref)
+    out = init.to(dev())
+    ops.gemm_tn(ld, rd, out, accumulate=True)
+    assert torch.equal(out.cpu(), init + ref)
+
+
 # ------------------------------------------------------------------------------------------ layernorm
 @pytest.mark.parametrize("M,D", [(1, 768), (777, 768), (320, 512), (111, 128), (50, 1024), (33, 200)])
 def test_layernorm_fwd_bwd(hip, M, D):

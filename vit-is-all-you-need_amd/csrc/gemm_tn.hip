@@ -341,6 +341,7 @@ static int auto_splits(int R, int P, int Q, int requested) {
 
 extern "C" long vitamd_gemm_tn_ws_bytes(int R, int P, int Q, int splits) {
   if (R <= 0 || P <= 0 || Q <= 0) return 0;
+  if (vitamd_gemm_tn_wide_ok(R, P, Q, splits)) return (long)vitamd_gemm_tn_wide_splits(R, P, Q) * P * Q * (long)sizeof(float);
   const long ntile = (long)((P + BP - 1) / BP) * ((Q + BQ - 1) / BQ);
   return (long)auto_splits(R, P, Q, splits) * ntile * BP * BQ * (long)sizeof(float);
 }
@@ -349,6 +350,9 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   if (a.R <= 0 || a.P <= 0 || a.Q <= 0 || a.ldl % 8 || a.ldr % 8 || a.ldl < a.P || a.ldr < a.Q || a.ldo < a.Q) return VITAMD_ERR_SHAPE;
   if ((size_t)(a.R + BR) * a.ldl * 2 >= 0x80000000ull || (size_t)(a.R + BR) * a.ldr * 2 >= 0x80000000ull) return VITAMD_ERR_SHAPE;
   if (!a.L || !a.Rm || !a.out) return VITAMD_ERR_ARG;
+  if (a.ws && a.ldl == a.P && a.ldr == a.Q && vitamd_gemm_tn_wide_ok(a.R, a.P, a.Q, a.splits) &&
+      a.ws_bytes >= (size_t)vitamd_gemm_tn_wide_splits(a.R, a.P, a.Q) * a.P * a.Q * sizeof(float))
+    return vitamd_gemm_tn_wide_launch(a, stream);
   const int tiles_p = (a.P + BP - 1) / BP, tiles_q = (a.Q + BQ - 1) / BQ;
   const int ntile = tiles_p * tiles_q;
   const int nsteps = (a.R + BR - 1) / BR;
