@@ -427,3 +427,20 @@ def test_vq_nearest_wide_codes(hip):
         for m in bad.tolist():                              # fp32-vs-fp64 near ties only
             assert abs(float(d2[m, idx[m]] - d2[m, ref[m]])) < 1e-4 * float(d2[m, ref[m]])
         assert len(bad) <= max(1, M // 100)
+
+
+def test_blocks_drop_rates_are_identity_in_eval(hip):
+    """Reference semantics: nn.Dropout / DropPath do nothing in eval mode (blocks.py:124-139).  A block built WITH drop rates
+    must reproduce the reference's (drop-free) golden output in eval mode, and refuse to train."""
+    import blocks as BK
+    case = load_golden("blocks_tiny.pt")["uvit_bias"]
+    m = BK.UViTBlock(dim=128, num_heads=2, qkv_bias=True, drop=0.1, attn_drop=0.1, drop_path=0.2)
+    m.load_state_dict(W.module_state(case["seed"], case["shapes"]), strict=True)
+    m = m.cuda().eval()
+    x = W.normal(case["seed"], "x", (3, 37, 128)).cuda()
+    with torch.no_grad():
+        y = m(x)
+    assert O.rel_l2(y.cpu(), case["y"]) < 2 * case["ref_bf16_floor"]["y"] + 2e-3
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(x)

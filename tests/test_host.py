@@ -126,8 +126,10 @@ def test_blocks_surface_state_dict_contract():
         m = getattr(BK, cls)(**kw)
         assert {k: list(v.shape) for k, v in m.state_dict().items()} == g[name]["shapes"], name
     assert isinstance(BK.ATTENTION_MODE, str)
-    with pytest.raises(NotImplementedError):
-        BK.UViTBlock(128, 2, drop_path=0.1)
+    blk = BK.UViTBlock(128, 2, drop=0.1, drop_path=0.1)        # rates accepted (configs carry them) ...
+    assert isinstance(blk.drop_path, BK.DropPath) and blk.mlp.drop.p == 0.1
+    with pytest.raises(NotImplementedError):                    # ... training with them is refused, loudly, before any kernel runs
+        blk(torch.zeros(1, 4, 128))
     with pytest.raises(NotImplementedError):
         BK.Attention(96, 2)            # head_dim 48
 

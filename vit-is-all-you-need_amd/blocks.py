@@ -7,8 +7,9 @@ flow of vitamd/functions.py (affine LayerNorm kernel, fused-QKV attention, GEMMs
 GELU / residual epilogues).
 
 Differences from the reference, stated: head_dim must be 64; the SDPA runs in bf16 (blocks.Attention
-upcasts q,k,v to fp32 first, blocks.py:100); the nn.Dropout / DropPath layers only accept rate 0 on this
-path (blocks.Attention's 'flash' mode ignores attn_drop anyway, blocks.py:98-103).
+upcasts q,k,v to fp32 first, blocks.py:100); non-zero drop / proj_drop / drop_path rates are accepted and are the
+identity in eval mode, but TRAINING with them raises (blocks.Attention's 'flash' mode ignores attn_drop anyway,
+blocks.py:98-103).
 
 The tokenizer wrappers of blocks.py:208-505 (TiTokEncoder / TiTokDecoder / TATiTokDecoder / VectorQuantizer)
 are here as well, over the same kernels: patch-embed GEMM with fused bias + positional embedding, fp32 affine
@@ -38,9 +39,14 @@ def _need_gelu(act_layer):
         raise NotImplementedError("only the erf-GELU activation is fused into the GEMM epilogues")
 
 
-def _need_zero(rate, what):
-    if rate != 0.0:
-        raise NotImplementedError(f"{what} > 0 is not implemented for the blocks.py surface")
+def _no_train_drop(mod, rates):
+    """Non-zero drop rates are accepted at construction (configs and checkpoints of the reference carry them) and are the
+    identity in eval mode, as in the reference; TRAINING with them is not built on this surface - fail loudly."""
+    if mod.training:
+        for what, rate in rates.items():
+            if rate:
+                raise NotImplementedError(f"training with {what} = {rate} is not implemented for the blocks.py surface "
+                                          "(transformer.py's dropout is: vitamd/functions.py)")
 
 
 def _heads(dim, num_heads):
@@ -101,20 +107,20 @@ class Attention(nn.Module):
         if qk_scale is not None and abs(qk_scale - head_dim ** -0.5) > 1e-12:
             raise NotImplementedError("only the default qk scale head_dim**-0.5 is built into the kernels")
         self.scale = qk_scale or head_dim ** -0.5
-        _need_zero(proj_drop, "proj_drop")
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)     # unused by the reference's 'flash' mode as well
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x):
+        _no_train_drop(self, {"proj_drop": self.proj_drop.p})     # attn_drop is unused by the reference's 'flash' mode as well
         return AttnProjFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.num_heads)
 
 
 def drop_path(x, drop_prob: float = 0., training: bool = False):
     if drop_prob == 0. or not training:
         return x
-    raise NotImplementedError("drop_path > 0 is not implemented for the blocks.py surface")
+    raise NotImplementedError("training with drop_path > 0 is not implemented for the blocks.py surface")
 
 
 class DropPath(nn.Module):
@@ -132,7 +138,6 @@ class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
         _need_gelu(act_layer)
-        _need_zero(drop, "drop")
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
         self.fc1 = nn.Linear(in_features, hidden_features)
@@ -141,6 +146,7 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        _no_train_drop(self, {"drop": self.drop.p})
         return MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
@@ -152,10 +158,9 @@ class UViTBlock(nn.Module):
         super().__init__()
         if norm_layer is not nn.LayerNorm:
             raise NotImplementedError("only nn.LayerNorm is supported")
-        _need_zero(drop_path, "drop_path")
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()     # as the reference (blocks.py:182)
         self.norm2 = norm_layer(dim)
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
@@ -166,6 +171,8 @@ class UViTBlock(nn.Module):
         return self._forward(x, skip)
 
     def _forward(self, x, skip=None):
+        _no_train_drop(self, {"drop": self.mlp.drop.p, "proj_drop": self.attn.proj_drop.p,
+                              "drop_path": getattr(self.drop_path, "drop_prob", 0.) or 0.})
         if self.skip_linear is not None:
             x = linear(torch.cat([x, skip], dim=-1), self.skip_linear.weight, self.skip_linear.bias)
         return BlockFn.apply(x, self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
