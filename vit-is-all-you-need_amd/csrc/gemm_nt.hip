@@ -1126,9 +1126,11 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const long big_tiles = (long)tiles_m * tiles_n;
   const long rem = big_tiles % CUS;
-  // off by default (single-stream profile: 233 us + 64 us for the split fc2 vs ~290 us unsplit: neutral);
-  // vitamd_set_debug bit 4 turns it on for every GEMM
-  const bool split_on = (p.dbg & 16) != 0;
+  // on for the fc2 forward GEMM only (fp32 residual epilogue, N = 768: 591 tiles = 2.31 rounds): single-stream profile
+  // 233 + 64 us split vs 323 us unsplit, whole-step A/B -0.2 ms; for every other GEMM the split LOSES (+0.9 ms with
+  // bit 4, which forces it everywhere): their tails are filled by the weight-gradient GEMMs of the side stream.
+  // vitamd_set_debug bit 7 turns it off, bit 4 forces it for every GEMM.
+  const bool split_on = (p.dbg & 16) != 0 || (p.epi == EPI_RESID_F32 && !(p.dbg & 128));
   if (p.tile == 0 && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
     const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
     const int rows_a = panels_a * 256;
