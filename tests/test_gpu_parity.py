@@ -444,3 +444,27 @@ def test_blocks_drop_rates_are_identity_in_eval(hip):
     m.train()
     with pytest.raises(NotImplementedError):
         m(x)
+
+
+def test_graphed_step_matches_eager(hip):
+    """hipGraph capture of forward + loss + backward (vitamd/graph.py) on BASELINE configs[0] (ViT-S, 32x32, batch 64):
+    replays on NEW inputs must reproduce the eager step on those inputs (atomics reorder fp32 sums: 1e-5, not bitwise)."""
+    import train_vit as TV
+    from vitamd.graph import GraphedStep
+    torch.manual_seed(0)
+    m = TV.ViTClassifier(TV.ViTConfig(32, 3, 16, "S", 1, 0.0), num_classes=10).cuda()
+    ce = torch.nn.functional.cross_entropy
+    xs = [W.normal(90 + i, "x", (64, 3, 32, 32)).cuda() for i in range(3)]
+    ys = [W.randint(90 + i, "y", (64,), 10).cuda() for i in range(3)]
+    step = GraphedStep(m, ce, xs[0], ys[0])
+    for i in (1, 2, 0):
+        loss_g = float(step(xs[i], ys[i]))
+        got = {k: p.grad.clone() for k, p in m.named_parameters()}
+        m.zero_grad(set_to_none=True)
+        loss_e = ce(m(xs[i]), ys[i]); loss_e.backward()
+        assert abs(loss_g - float(loss_e)) < 1e-6
+        for k, p in m.named_parameters():
+            assert O.rel_l2(got[k].cpu(), p.grad.cpu()) < 1e-5, k
+    from vitamd.lib import VitamdError
+    with pytest.raises(VitamdError):
+        step(xs[0][:32], ys[0][:32])
