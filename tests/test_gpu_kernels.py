@@ -107,6 +107,44 @@ def test_gemm_nt_epilogues(hip, tile):
     assert O.rel_l2(got[:, extra:], want) < 1e-3
 
 
+@pytest.mark.parametrize("M", [256 * 197, 50000, 320 * 100 + 7])
+def test_gemm_nt_tall_tile_exact(hip, M):
+    """N = 768 outputs at large M are dispatched to the 320x256-tile kernel (fewer rounds of the 256 CUs); integer operands
+    make the bf16 / fp32 results exact, so any mis-mapped row or column shows.  Checked against the 256x256 kernel too."""
+    from vitamd import ops
+    N, K = 768, 128
+    a, b = ints((M, K), -1, 1, 41), ints((N, K), -1, 1, 42)
+    bias = ints((N,), -3, 3, 43)
+    res = ints((M, N), -7, 7, 44)
+    acc = a @ b.t()
+    ad, bd = a.to(dev(), BF16), b.to(dev(), BF16)
+    y = ops.gemm_nt(ad, bd, ops.EPI_BIAS_BF16, bias=bias.to(dev()))
+    assert torch.equal(y.float().cpu(), acc + bias)
+    assert torch.equal(y, ops.gemm_nt(ad, bd, ops.EPI_BIAS_BF16, bias=bias.to(dev()), tile=2))
+    y = ops.gemm_nt(ad, bd, ops.EPI_RESID_F32, bias=bias.to(dev()), aux=res.to(dev()))
+    assert torch.equal(y.cpu(), acc + bias + res)
+
+
+def test_gemm_nt_tall_tile_gelu_epilogues_match_256(hip):
+    """N = 3072 at large M also takes the 320-row tile (a tie in rounds x rows, higher FLOP per staged byte): the GELU / stored
+    derivative / multiply epilogues must give bit-identical results to the 256-row kernel (same per-element arithmetic)."""
+    from vitamd import ops
+    M, N, K = 20380, 3072, 128
+    a, b = r16(randn((M, K), 51)).to(dev(), BF16), r16(randn((N, K), 52, 0.1)).to(dev(), BF16)
+    bias = randn((N,), 53).to(dev())
+    aux = r16(randn((M, N), 54, 0.5)).to(dev(), BF16)
+    for epi in (ops.EPI_GELU, ops.EPI_GELU_DG):
+        o1, h1 = ops.gemm_nt(a, b, epi, bias=bias)
+        o2, h2 = ops.gemm_nt(a, b, epi, bias=bias, tile=2)
+        assert torch.equal(o1, o2) and torch.equal(h1, h2)
+    for epi in (ops.EPI_DGELU, ops.EPI_DMUL):
+        c1, c2 = torch.zeros(N, device=dev()), torch.zeros(N, device=dev())
+        y1 = ops.gemm_nt(a, b, epi, aux=aux, colsum=c1)
+        y2 = ops.gemm_nt(a, b, epi, aux=aux, colsum=c2, tile=2)
+        assert torch.equal(y1, y2)
+        assert O.rel_l2(c1.cpu(), c2.cpu()) < 1e-5          # column sums: atomics, order differs
+
+
 def test_gemm_nt_rejects_bad_shapes(hip):
     from vitamd import ops, lib
     a = torch.zeros((64, 100), device=dev(), dtype=BF16)

@@ -161,12 +161,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
     else __builtin_nontemporal_store((val), (ptr));                                            \
   } while (0)
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn,
+template <int EPI, int MT = 8>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&acc)[MT][4], int m0, int n0, int wm, int wn,
                                                    int lane, int tid, int wave, char* smem) {
   constexpr int BN = 256;
   __syncthreads();                       // every wave is done reading the operand buffers
-  char* tile = smem + wave * 16384;      // wave-private image
+  char* tile = smem + wave * (MT * 2048);   // wave-private image: [16*MT rows][64 bf16]
   const int mloc = lane & 15, g = lane >> 4;
   const int ncol_acc = n0 + wn * 64 + 4 * g;
   // ---- 1. bias (+ bf16 rounding of the Linear output) in the accumulator layout, pack, write to LDS
@@ -182,7 +182,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const f32x4 v = acc[i][j] + bias4;
       const int row = 16 * i + mloc;
       const int chunk = (2 * j + (g >> 1)) ^ (row & 7);
@@ -202,20 +202,20 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
   const int n = n0 + wn * 64 + 8 * (pc ^ rsub);
   const bool ncol_ok = n < p.N;           // N % 8 == 0 is required by the row epilogue
   const int nc = ncol_ok ? n : 0;
-  const int mbase = m0 + wm * 128 + rsub;
+  const int mbase = m0 + wm * (16 * MT) + rsub;
   // ---- 2a. the accumulators are dead now: issue EVERY auxiliary load of the tile up front (clamped
   // rows, unconditional) so their latency overlaps the LDS round trip instead of serialising per row
-  u32x4 auxb[EPI == EPI_DGELU ? 16 : 1];
-  f32x4 auxf[(EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) ? 32 : 1];
+  u32x4 auxb[EPI == EPI_DGELU ? 2 * MT : 1];
+  f32x4 auxf[(EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) ? 4 * MT : 1];
   if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 2 * MT; ++it) {
       const int m = min(mbase + 8 * it, p.M - 1);
       auxb[it] = *(const u32x4*)((const __bf16*)p.aux + (size_t)m * ldo + nc);
     }
   } else if constexpr (EPI == EPI_RESID_F32) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 2 * MT; ++it) {
       const int m = min(mbase + 8 * it, p.M - 1);
       const float* rp = (const float*)p.aux + (size_t)m * ldo + nc;
       auxf[2 * it] = *(const f32x4*)rp;
@@ -223,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
     }
   } else if constexpr (EPI == EPI_PATCH_F32) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 2 * MT; ++it) {
       const int m = min(mbase + 8 * it, p.M - 1);
       const float* pp = (const float*)p.aux + (size_t)(m % p.n_patches) * ldo + nc;
       auxf[2 * it] = *(const f32x4*)pp;
@@ -231,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
     }
   }
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < 2 * MT; ++it) {
     const int rloc = rsub + 8 * it;
     const int m = mbase + 8 * it;
     const u32x4 v = *(const u32x4*)(tile + rloc * 128 + pc * 16);
@@ -527,11 +527,14 @@ int launch_ring(const GemmNtArgs& p, hipStream_t stream) {
 // the ds_reads of the NEXT group's fragments, THEN runs its 8 MFMAs, so VMEM issue, LDS latency
 // and matrix work overlap inside one wave instead of arriving in bursts behind the barrier
 // (PMC on the burst form: MFMA pipe 38 % busy, waves 49 % issue-stalled; profiles/r01).
-template <int EPI, int ABL = 0>   // ABL: timing-only ablations (1 = no MFMA, 2 = no LDS-DMA, 3 = no ds_read); results are garbage
+// MT = 16-row MFMA tiles per wave along M: 8 -> 256x256 tile; 10 -> 320x256 (wave tile 160x64, 160 accumulator registers), used for
+// N = 768 outputs where 256-row tiles need 2.31 rounds of the 256 CUs and 320-row tiles 1.85 (dispatch_tile picks by rounds x rows)
+template <int EPI, int ABL = 0, int MT = 8>   // ABL: timing-only ablations (1 = no MFMA, 2 = no LDS-DMA, 3 = no ds_read); results are garbage
 __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
-  constexpr int WTM = 128, WTN = 64, MT = 8, NT = 4;
-  constexpr int PPW = 8;                       // 1-KiB pieces (8 rows x 128 B) per wave per K-tile
+  constexpr int BM = 32 * MT, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int WTM = 16 * MT, WTN = 64, NT = 4;
+  constexpr int APW = MT / 2;                  // A pieces per wave per K-tile
+  constexpr int PPW = APW + 4;                 // 1-KiB pieces (8 rows x 128 B) per wave per K-tile
   constexpr int BUF_BYTES = (BM + BN) * 128;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
   for (int i = 0; i < PPW; ++i) {
     const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int logical = (lane & 7) ^ (row & 7);
-    const int grow = (i < 4) ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);
+    const int grow = (i < APW) ? min(m0 + row, p.M - 1) : min(n0 + row - BM, p.N - 1);
     voff[i] = (unsigned)grow * (unsigned)(K * 2) + logical * 16;
   }
 
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
   {  // prologue: whole tile 0
     char* base = smem + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) buf_glds16(i < 4 ? rsrcA : rsrcB, base + i * NW * 1024, voff[i], 0);
+    for (int i = 0; i < PPW; ++i) buf_glds16(i < APW ? rsrcA : rsrcB, base + i * NW * 1024, voff[i], 0);
   }
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
@@ -604,14 +607,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) if (ABL != 3 || kt == 0) aq[0][i] = *(const bf16x8*)(buf + a_off + i * 2048);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int ks = g >> 2, pr = g & 3;
-      if (more && ABL != 2) {
-        if constexpr (ABL == 5) stg[g] = buf_load16(g < 4 ? rsrcA : rsrcB, voff[g], soff);
-        else buf_glds16(g < 4 ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
+    for (int g = 0; g < MT; ++g) {
+      const int ks = g / APW, pr = g % APW;
+      if (more && ABL != 2 && g < PPW) {
+        if constexpr (ABL == 5) stg[g] = buf_load16(g < APW ? rsrcA : rsrcB, voff[g], soff);
+        else buf_glds16(g < APW ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
       }
-      if (g < 7) {
-        const int ks2 = (g + 1) >> 2, pr2 = (g + 1) & 3;
+      if (g < MT - 1) {
+        const int ks2 = (g + 1) / APW, pr2 = (g + 1) % APW;
 #pragma unroll
         for (int i = 0; i < 2; ++i) if (ABL != 3 || kt == 0) aq[(g + 1) & 1][i] = *(const bf16x8*)(buf + ((a_off + (2 * pr2 + i) * 2048) ^ (ks2 * 64)));
       }
@@ -632,26 +635,27 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
     if constexpr (ABL == 5) {
       if (more) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) *(u32x4*)(nbase + g * NW * 1024 + lane * 16) = stg[g];
+        for (int g = 0; g < PPW; ++g) *(u32x4*)(nbase + g * NW * 1024 + lane * 16) = stg[g];
       }
     }
   }
   if constexpr (EPI == EPI_F32) gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
-  else if (p.N % 8 == 0 && p.ldo % 8 == 0) gemm_epilogue_rows<EPI>(p, acc, m0, n0, wm, wn, lane, tid, wave, smem);
+  else if (p.N % 8 == 0 && p.ldo % 8 == 0) gemm_epilogue_rows<EPI, MT>(p, acc, m0, n0, wm, wn, lane, tid, wave, smem);
   else gemm_epilogue<BN, WM, WN, WTM, WTN, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
 }
 
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, int MT = 8>
 int launch_pipe(const GemmNtArgs& p, hipStream_t stream) {
-  constexpr int lds = 2 * 512 * 128;
-  auto kern = gemm_nt_pipe_kernel<EPI, ABL>;
+  constexpr int BM = 32 * MT;
+  constexpr int lds = (2 * (BM + 256) * 128 > 8 * MT * 2048) ? 2 * (BM + 256) * 128 : 8 * MT * 2048;   // operand stages / epilogue images
+  auto kern = gemm_nt_pipe_kernel<EPI, ABL, MT>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return VITAMD_ERR_LAUNCH;
     attr_done = true;
   }
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, p);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
@@ -1065,6 +1069,19 @@ int launch(const GemmNtArgs& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
+// 320-row tiles instead of 256-row ones when that does not need more (rounds of 256 CUs) x (rows per tile): at M = 50 432,
+// N = 768 outputs take 591 tiles = 3 rounds of 256 rows but 474 tiles = 2 rounds of 320 rows (-0.6 ms/step); N = 3072 is a tie
+// (10 x 256 = 8 x 320), N = 2304 stays on 256 (7 x 256 < 6 x 320; forcing 320 there measured equal).  A 384-row tile would need
+// 192 accumulator registers (compiles to 256 VGPRs) and a two-pass epilogue, and quantises worse at this M.
+// dbg bit 19 disables the tall tile (A/B knob).
+static bool prefer_tall(const GemmNtArgs& p) {
+  if ((p.dbg & 0x80000) || p.N % 8 != 0 || p.ldo % 8 != 0 || p.K % 64 != 0) return false;
+  if (p.epi != EPI_BIAS_BF16 && p.epi != EPI_RESID_F32 && p.epi != EPI_GELU && p.epi != EPI_DGELU) return false;
+  const long tn = (p.N + 255) / 256;
+  const long r256 = (((p.M + 255) / 256) * tn + 255) / 256, r320 = (((p.M + 319) / 320) * tn + 255) / 256;
+  return r320 * 320 <= r256 * 256;     // ties go to the tall tile: 142 instead of 128 FLOP per staged byte (whole-step A/B: -0.5 ms on the N = 3072 GEMMs alone)
+}
+
 template <int EPI>
 int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   // tile selector: 0 = auto, 1 = 256x128 ring kernel (2 workgroups/CU), 256 = 256x256 double-buffered,
@@ -1080,6 +1097,9 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   if (tile == 1) return ring_ok ? launch_ring<256, 128, 2, 2, EPI>(p, stream) : VITAMD_ERR_SHAPE;
   if (tile == 2) {
     if (!(ring_ok && p.K % 64 == 0)) return VITAMD_ERR_SHAPE;
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU) {
+      if (p.tile == 0 && prefer_tall(p)) return launch_pipe<EPI, 0, 10>(p, stream);
+    }
     return (p.dbg & 0x20000000) ? launch_pipe<EPI, 5>(p, stream) : launch_pipe<EPI>(p, stream);   // dbg bit 29: A/B of the staging path
   }
   if constexpr (EPI != EPI_F32) {
@@ -1130,7 +1150,7 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   // 233 + 64 us split vs 323 us unsplit, whole-step A/B -0.2 ms; for every other GEMM the split LOSES (+0.9 ms with
   // bit 4, which forces it everywhere): their tails are filled by the weight-gradient GEMMs of the side stream.
   // vitamd_set_debug bit 7 turns it off, bit 4 forces it for every GEMM.
-  const bool split_on = (p.dbg & 16) != 0 || (p.epi == EPI_RESID_F32 && !(p.dbg & 128));
+  const bool split_on = ((p.dbg & 16) != 0 || (p.epi == EPI_RESID_F32 && !(p.dbg & 128))) && !(p.tile == 0 && prefer_tall(p));
   if (p.tile == 0 && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
     const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
     const int rows_a = panels_a * 256;
