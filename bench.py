@@ -70,24 +70,27 @@ def kernel_roofline(dev):
         tot_flops += flops
         tot_ms += ms
     achieved = tot_flops / tot_ms / 1e9
-    return {"bound": "mfma", "kernel": "gemm_nt_pipe_kernel<256x256x64> (the 6 NT GEMM launches of one layer)",
+    return {"bound": "mfma", "kernel": "gemm_nt_pipe_kernel (256x256x64 / 320x256x64 tiles; the 6 NT GEMM launches of one layer)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": (pmc_traffic() or {}).get("bytes_per_launch"),
             "traffic_detail": pmc_traffic(), "per_shape_tflops": detail}
 
 
+PMC_PROFILE = os.path.join("profiles", "r01", "h_final_pmc_hbm_traffic.json")
+
+
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/e_final_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same
-    bench command, 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction), averaged over the six NT GEMM
-    launches of a layer (3 plain + gelu + residual + dgelu).  None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "e_final_pmc_hbm_traffic.json")
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this same bench command folded by tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+    correction), averaged over the six NT GEMM launches of a layer: QKV (256-row tiles), fc1+GELU, fc2+residual,
+    fc2-dgrad x gelu', fc1-dgrad and QKV-dgrad (320-row tiles).  None if the profile is absent."""
     try:
-        prof = json.load(open(path))
-        per = {k: v["hbm_MB_avg_corrected(2*fetch+write)"] for k, v in prof.items() if "gemm_nt_pipe_kernel<" in k}
-        mb = (3 * per[[k for k in per if "<0, 0>" in k][0]] + sum(per[[k for k in per if f"<{e}, 0>" in k][0]] for e in (1, 2, 3))) / 6
+        prof = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+        per = {k.split("gemm_nt_pipe_kernel")[1].split("(")[0]: v["hbm_MB_avg_corrected(2*fetch+write)"]
+               for k, v in prof.items() if "gemm_nt_pipe_kernel<" in k}
+        mb = (per["<0, 0, 8>"] + per["<1, 0, 10>"] + per["<2, 0, 10>"] + per["<3, 0, 10>"] + 2 * per["<0, 0, 10>"]) / 6
         return {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int((3 * 339 + 702 + 625 + 702) / 6 * 1e6),
-                "source": "profiles/r01/e_final_pmc_hbm_traffic.json"}
+                "source": PMC_PROFILE}
     except Exception:
         return None
 
