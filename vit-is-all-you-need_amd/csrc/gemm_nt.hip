@@ -10,11 +10,12 @@
 // mfma_f32_16x16x32_bf16 with A/B swapped (D[n][m]) so each lane owns 4 consecutive output columns.
 //
 // Kernels in this file (DESIGN.md section 4 has the measurements):
-//   gemm_nt_pipe_kernel     256x256x64, 8 waves, grouped DMA/ds_read/MFMA issue        <- production (auto, tile=2)
+//   gemm_nt_pipe_kernel     256x256x64 or 320x256x64 (MT = 8 / 10), 8 waves, grouped DMA/ds_read/MFMA issue   <- production (auto, tile=2)
+//                           the 320-row form wherever it needs no more rounds x rows of the 256 CUs (prefer_tall): -1.1 ms/step
 //   gemm_nt_kernel          plain double-buffered; 128x128 instance serves small problems (auto) / tile=256
-//   gemm_nt_persist_kernel  pipe + persistent tile loop with cross-tile prefetch         (tile=6, neutral)
+//   gemm_nt_persist_kernel  pipe + persistent tile loop with cross-tile prefetch         (tile=6, +0.4 ms/step)
 //   gemm_nt_ring_kernel     256x128, BK=32, 3-stage ring, 2 workgroups per CU            (tile=1, slower)
-//   gemm_nt_deep_kernel     256x256, BK=32, 3..5-stage ring                              (tile=3..5, neutral)
+//   gemm_nt_deep_kernel     256x256, BK=32, 3..5-stage ring                              (tile=3..5, much slower on the whole step)
 // Epilogues: gemm_epilogue_rows (LDS-transposed, row-major 16-B accesses; production),
 //            epilogue_rows_halves (same in 64-KiB of LDS; persistent kernel), gemm_epilogue (direct; small tiles).
 #include "common.h"
