@@ -175,6 +175,26 @@ def test_gemm_tn_exact_integers(hip, R, P, Q, splits):
     assert torch.equal(out.cpu(), l.t() @ r)
 
 
+@pytest.mark.parametrize("dbg_bits", [64, 5 << 26])
+@pytest.mark.parametrize("R,P,Q", [(1000, 256, 256), (4133, 768, 512), (300, 200, 136)])
+def test_gemm_tn_alternative_kernels_exact_integers(hip, R, P, Q, dbg_bits):
+    """The measured alternatives of the weight-gradient GEMM kept behind vitamd_set_debug: bit 6 = mfma_f32_16x16x32 form,
+    bits 26-28 = 5 = LDS-DMA staging of the 32x32x16 form.  Same exactness check as the production kernel."""
+    import ctypes
+    from vitamd import ops, lib
+    L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+    l, r = ints((R, P), -2, 2, 61), ints((R, Q), -3, 3, 62)
+    ref = l.t() @ r
+    L.vitamd_set_debug(dbg_bits)
+    try:
+        out = torch.full((P, Q), 7.0, device=dev())
+        ops.gemm_tn(l.to(dev(), BF16), r.to(dev(), BF16), out, accumulate=False)
+        torch.cuda.synchronize()
+    finally:
+        L.vitamd_set_debug(0)
+    assert torch.equal(out.cpu(), ref)
+
+
 @pytest.mark.parametrize("R,P,Q", [(4096, 256, 384), (5000, 512, 768), (8197, 768, 768), (4100, 256, 1152)])
 def test_gemm_tn_wide_tile_exact_integers(hip, R, P, Q):
     """The opt-in 256x384-tile kernel (vitamd_set_debug bit 25; P % 256 == 0, Q % 384 == 0, R >= 4096, auto splits): integer
