@@ -523,8 +523,8 @@ int launch_ring(const GemmNtArgs& p, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------
 // Main kernel: 256x256 tile, 8 waves (2x4, wave tile 128x64), BK = 64, two LDS buffers (128 KiB).
-// The K-tile is cut into 8 groups of 8 MFMAs (one A row-pair x four B fragments x one 32-deep
-// k-substep).  Each group FIRST issues its share of the next tile's LDS-DMA (one 1-KiB piece) and
+// The K-tile is cut into 4 groups of 16 (20) MFMAs (half the A fragments x four B fragments x one 32-deep
+// k-substep; 8 groups of 8 originally).  Each group FIRST issues its share of the next tile's LDS-DMA (one 1-KiB piece) and
 // the ds_reads of the NEXT group's fragments, THEN runs its 8 MFMAs, so VMEM issue, LDS latency
 // and matrix work overlap inside one wave instead of arriving in bursts behind the barrier
 // (PMC on the burst form: MFMA pipe 38 % busy, waves 49 % issue-stalled; profiles/r01).
@@ -601,35 +601,43 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(const GemmNtArgs p) {
     const bool more = kt + 1 < nkt;
     const int soff = (kt + 1) * 128;
 
-    bf16x8 bq[2][NT], aq[2][2];
+    // A fragments per group.  MT/2: four groups of 16 (20) MFMAs per K-tile, each ~256 (320) MFMA cycles long, which covers the
+    // latency of the next group's ds_reads with room to spare; the original 8 (10) groups of 8 MFMAs (ABL 7) were 0.2 ms/step slower
+    constexpr int GA = (ABL == 7) ? 2 : MT / 2;
+    constexpr int GPK = APW * 2 / GA;               // groups per 32-deep k-substep   (APW = MT / 2)
+    constexpr int NG = 2 * GPK;                     // groups per K-tile
+    bf16x8 bq[2][NT], aq[2][GA];
     u32x4 stg[ABL == 5 ? PPW : 1];    // ABL 5: stage the next tile through VGPRs + ds_write instead of LDS-DMA (correct results)
 #pragma unroll
     for (int j = 0; j < NT; ++j) if (ABL != 3 || kt == 0) bq[0][j] = *(const bf16x8*)(buf + b_off + j * 2048);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) if (ABL != 3 || kt == 0) aq[0][i] = *(const bf16x8*)(buf + a_off + i * 2048);
+    for (int i = 0; i < GA; ++i) if (ABL != 3 || kt == 0) aq[0][i] = *(const bf16x8*)(buf + a_off + i * 2048);
 #pragma unroll
-    for (int g = 0; g < MT; ++g) {
-      const int ks = g / APW, pr = g % APW;
-      if (more && ABL != 2 && g < PPW) {
-        if constexpr (ABL == 5) stg[g] = buf_load16(g < APW ? rsrcA : rsrcB, voff[g], soff);
-        else buf_glds16(g < APW ? rsrcA : rsrcB, nbase + g * NW * 1024, voff[g], soff);
-      }
-      if (g < MT - 1) {
-        const int ks2 = (g + 1) / APW, pr2 = (g + 1) % APW;
+    for (int g = 0; g < NG; ++g) {
+      const int ks = g / GPK, pr = g % GPK;
+      if (more && ABL != 2) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) if (ABL != 3 || kt == 0) aq[(g + 1) & 1][i] = *(const bf16x8*)(buf + ((a_off + (2 * pr2 + i) * 2048) ^ (ks2 * 64)));
+        for (int q = g * PPW / NG; q < (g + 1) * PPW / NG; ++q) {     // this group's share of the next tile's pieces
+          if constexpr (ABL == 5) stg[q] = buf_load16(q < APW ? rsrcA : rsrcB, voff[q], soff);
+          else buf_glds16(q < APW ? rsrcA : rsrcB, nbase + q * NW * 1024, voff[q], soff);
+        }
       }
-      if (g == 1) {
+      if (g < NG - 1) {
+        const int ks2 = (g + 1) / GPK, pr2 = (g + 1) % GPK;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) if (ABL != 3 || kt == 0) aq[(g + 1) & 1][i] = *(const bf16x8*)(buf + ((a_off + (GA * pr2 + i) * 2048) ^ (ks2 * 64)));
+      }
+      if (g == (NG > 4 ? 1 : 0)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) if (ABL != 3 || kt == 0) bq[1][j] = *(const bf16x8*)(buf + ((b_off + j * 2048) ^ 64));
       }
       if constexpr (ABL == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < GA; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           if constexpr (ABL == 1) { asm volatile("" ::"v"(bq[ks][j]), "v"(aq[g & 1][i])); }
-          else acc[2 * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[g & 1][i], acc[2 * pr + i][j], 0, 0, 0);
+          else acc[GA * pr + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], aq[g & 1][i], acc[GA * pr + i][j], 0, 0, 0);
       if constexpr (ABL == 4) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
