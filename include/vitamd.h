@@ -97,7 +97,7 @@ int vitamd_layernorm_affine_bwd_f32(const float* dy, const float* x, const float
 
 /* ---- Attention on the packed fused-QKV layout ------------------------------------------------
  * qkv bf16 [B,N,3,H,64] (output-channel order (qkv, head, dh) of transformer.py:27), o bf16 [B,N,H*64],
- * lse2 fp32 [B,H,N].  head_dim must be 64, N <= 512.  causal != 0 applies the strictly-upper -inf
+ * lse2 fp32 [B,H,N].  head_dim must be 64, N <= 16384 (N <= 512: one LDS-resident chunk per head; longer: both sides tiled).  causal != 0 applies the strictly-upper -inf
  * mask of transformer.py:22-25.   replaces transformer.py:27-29 (rearrange + SDPA + rearrange).
  * dropout_p in [0,1): dropout on the softmax probabilities (SDPA's dropout_p); the mask is a stateless
  * hash of (seed, batch, head, query, key), so the backward call regenerates it from the same seed. */

@@ -44,7 +44,7 @@ def test_fc2_dropout_mask_is_shared_by_forward_and_backward(hip):
     assert torch.all(ops.linear_dropout_resid(a, w, bias, resid, (0.0, 0)).cpu() == 2.0)
 
 
-@pytest.mark.parametrize("N", [64, 197, 288])
+@pytest.mark.parametrize("N", [64, 197, 288, 600])
 def test_attention_dropout_mask_is_shared_by_forward_and_backward(hip, N):
     """q = k = 0 makes P uniform (1/N); one-hot V rows expose (P o mask)[q, k] for k < 64 in the
     forward output, and dO = 1 exposes the same mask's column sums in dV."""

@@ -285,6 +285,30 @@ def test_attention_fwd_bwd(hip, B, N, H, causal):
         assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 1.2e-2, name
 
 
+@pytest.mark.parametrize("B,N,H,causal", [(1, 513, 1, False), (2, 577, 2, False), (1, 1024, 2, True), (1, 640, 1, True), (1, 1500, 1, False)])
+def test_attention_long_sequences(hip, B, N, H, causal):
+    """N > 512: the two-sided-tiled kernels (K/V or Q/dO streamed through LDS in 512-row chunks, online softmax state and
+    the dQ / dK / dV accumulators carried across chunks).  Same checks as the single-chunk kernels."""
+    from vitamd import ops
+    qkv = r16(randn((B * N, 3 * H * 64), 131 + N, 1.5))
+    d_o = r16(randn((B * N, H * 64), 132 + N))
+    o_ref, dqkv_ref = _attn_ref(qkv, B, N, H, causal, d_o)
+    qd = qkv.to(dev(), BF16)
+    o, lse = ops.attention_fwd(qd, B, N, H, causal)
+    assert O.rel_l2(o.float().cpu(), o_ref) < 6e-3
+    q, k, _ = O.split_qkv(qkv.view(B, N, -1), H)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
+    assert O.rel_l2(lse.cpu(), torch.logsumexp(s, -1) / math.log(2.0)) < 1e-4
+    dbias = torch.zeros((3 * H * 64,), device=dev())
+    dqkv = ops.attention_bwd(qd, o, lse, d_o.to(dev(), BF16), B, N, H, causal, dbias=dbias).float().cpu()
+    assert O.rel_l2(dbias.cpu(), dqkv.sum(0)) < 2e-4
+    D = H * 64
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 1.2e-2, name
+
+
 def test_attention_softmax_spike(hip):
     """A key that dominates late in the sequence forces the online-softmax rescale branch."""
     from vitamd import ops

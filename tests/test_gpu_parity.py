@@ -265,7 +265,7 @@ def test_tokenizer_vs_reference_golden(hip, name):
     assert not bad, bad[:8]
 
 
-@pytest.mark.parametrize("preset,seq,batch", [("L", 65, 2), ("S", 288, 2), ("B", 256, 1)])
+@pytest.mark.parametrize("preset,seq,batch", [("L", 65, 2), ("S", 288, 2), ("B", 256, 1), ("B", 577, 1)])   # 577 = ViT-B/16 at 384 px: long-sequence attention
 def test_single_layer_presets_vs_oracle(hip, preset, seq, batch):
     """One layer of each reference preset (transformer.py:56-58) at the sequence lengths the tokenizers
     use (288 = TiTok, 256 = ViT-VQGAN) against the oracle's bf16-flow emulation."""

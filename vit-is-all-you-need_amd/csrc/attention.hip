@@ -1,7 +1,8 @@
 // Scaled-dot-product attention forward / backward for the packed fused-QKV layout of the
 // reference (transformer.py:26-29): qkv [B, N, 3, H, 64] bf16 straight out of the QKV GEMM,
 // output o [B, N, H*64] bf16 — the einops split/merge copies of transformer.py:27,29 never exist.
-// softmax(q k^T / sqrt(dh) [+ causal -inf mask, transformer.py:22-25]) v ; dh = 64 ; N <= 512.
+// softmax(q k^T / sqrt(dh) [+ causal -inf mask, transformer.py:22-25]) v ; dh = 64 ; N <= 512 in one LDS-resident
+// chunk per head, longer sequences (to 16 384) through the two-sided tiling of the *_long_kernel forms.
 //
 // gfx950 design.  One workgroup (4 waves) per (batch, head); the whole K/V (or Q/dO) of the head
 // sits in LDS as [N][64] bf16 tiles (128-B rows, LDS-DMA staged, chunk index XOR-swizzled so BOTH
@@ -20,7 +21,8 @@
 namespace {
 
 constexpr int DH = 64;
-constexpr int MAX_N = 512;
+constexpr int MAX_N = 512;        // single-chunk kernels; longer sequences (up to MAX_N_LONG) take the *_long_kernel forms
+constexpr int MAX_N_LONG = 16384;
 constexpr float NEG_BIG = -1.0e30f;
 
 typedef LDS_AS bf16x4* lds_bf16x4_ptr;
@@ -484,8 +486,278 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------ long sequences (N > 512)
+// Same three algorithms with both sides tiled: the grid gets a second dimension over blocks of 128 "lane-side" rows
+// (one 32-row block per wave: queries in forward / dQ, keys in dK-dV) and the kernel loops over LDS-staged chunks of
+// CH = 512 rows of the other side (K,V or Q,dO + lse/delta), re-staging between two barriers.  The per-wave state
+// (online-softmax m, l and the O accumulator; dQ; dK and dV) lives in registers across chunks.  K/V (Q/dO) are read
+// ceil(N/128) times, from L2 after the first.
+constexpr int CH = 512;
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  const int nt = (N + 31) / 32;
+  char* ktile = smem;
+  char* vtile = smem + CH * 128;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  const int qb = blockIdx.y * 4 + wave;
+  const bool active = qb < nt;                       // idle waves still stage and synchronise
+  const int q0 = qb * 32, qrow = q0 + (lane & 31);
+  const float c = a.scale_log2e;
+  bf16x8 qf[4];
+  if (active) load_lane_frags(qbase, D3, N, q0, lane, qf);
+  f32x16 oacc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+  const int t_end = a.causal ? min(nt, qb + 1) : nt;  // global key-tile bound
+  for (int k0 = 0; k0 < N; k0 += CH) {
+    const int rows = min(CH, N - k0), ntc = (rows + 31) / 32;
+    __syncthreads();                                   // everyone is done with the previous chunk
+    stage_tile(qbase + D + (size_t)k0 * D3, D3, rows, ntc * 32, ktile, wave, lane);
+    stage_tile(qbase + 2 * D + (size_t)k0 * D3, D3, rows, ntc * 32, vtile, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) continue;
+    for (int T = 0; T < ntc && k0 / 32 + T < t_end; ++T) {
+      const int key0 = k0 + 32 * T;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s, 0, 0, 0);
+      if (key0 + 32 > N || (a.causal && key0 / 32 == qb)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + acc_row(r, lane);
+          if (!(key < N && (!a.causal || key <= qrow))) s[r] = NEG_BIG;
+        }
+      }
+      float tmax = max16(s);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
+      const float mnew = fmaxf(m, tmax);
+      const float alpha = fast_exp2(m - mnew);
+      m = mnew;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = fast_exp2(__builtin_fmaf(s[r], c, -mnew));
+        psum += s[r];
+        if constexpr (DROP) s[r] *= attn_keep(a, blockIdx.x, min(qrow, N - 1), min(key0 + acc_row(r, lane), N - 1));
+      }
+      l = l * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 pf = acc_to_frag(s, sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vtile, T, sidx, dt, lane), pf, oacc[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  store_rows_T(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv);
+  if (lane < 32 && qrow < N) a.lse2[((size_t)b * a.H + hh) * N + qrow] = m + log2f(l);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_long_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  const int nt = (N + 31) / 32;
+  char* ktile = smem;
+  char* vtile = smem + CH * 128;
+  char* oimg = smem + 2 * CH * 128 + wave * 4096;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  const __bf16* obase = a.o + (size_t)b * N * D + hh * DH;
+  const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  const int qb = blockIdx.y * 4 + wave;
+  const bool active = qb < nt;
+  const int q0 = qb * 32, qrow = q0 + (lane & 31);
+  const float c = a.scale_log2e;
+  bf16x8 qf[4], dof[4];
+  float delta = 0.f, lse2 = 0.f;
+  if (active) {
+    bf16x8 of[4];
+    load_lane_frags(qbase, D3, N, q0, lane, qf);
+    load_lane_frags(dobase, D, N, q0, lane, dof);
+    load_lane_frags(obase, D, N, q0, lane, of);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[kk][j] * (float)of[kk][j];
+    delta += __shfl_xor(delta, 32, 64);
+    const size_t stat = ((size_t)b * a.H + hh) * N + min(qrow, N - 1);
+    lse2 = a.lse2[stat];
+    if (lane < 32 && qrow < N) a.delta[stat] = delta;
+  }
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  const int t_end = a.causal ? min(nt, qb + 1) : nt;
+  for (int k0 = 0; k0 < N; k0 += CH) {
+    const int rows = min(CH, N - k0), ntc = (rows + 31) / 32;
+    __syncthreads();
+    stage_tile(qbase + D + (size_t)k0 * D3, D3, rows, ntc * 32, ktile, wave, lane);
+    stage_tile(qbase + 2 * D + (size_t)k0 * D3, D3, rows, ntc * 32, vtile, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) continue;
+    for (int T = 0; T < ntc && k0 / 32 + T < t_end; ++T) {
+      const int key0 = k0 + 32 * T;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vtile, T, kk, lane), dof[kk], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
+        float dpr = dp[r];
+        if constexpr (DROP) dpr *= attn_keep(a, blockIdx.x, min(qrow, N - 1), min(key0 + acc_row(r, lane), N - 1));
+        s[r] = pexp * (dpr - delta);
+      }
+      if (key0 + 32 > N || (a.causal && key0 / 32 == qb)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + acc_row(r, lane);
+          if (!(key < N && (!a.causal || key <= qrow))) s[r] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 dsf = acc_to_frag(s, sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ktile, T, sidx, dt, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  float csum_q = 0.f;
+  if (active) store_rows_T_lds(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale, oimg, a.dbias ? &csum_q : nullptr);
+  if (a.dbias && active) atomicAdd(a.dbias + hh * DH + lane, csum_q);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_long_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  const int nt = (N + 31) / 32;
+  char* qtile = smem;
+  char* dotile = smem + CH * 128;
+  float* lse_s = (float*)(smem + 2 * CH * 128);
+  float* delta_s = lse_s + CH;
+  char* oimg = smem + 2 * CH * 128 + 2 * CH * 4 + wave * 4096;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  const int kb = blockIdx.y * 4 + wave;
+  const bool active = kb < nt;
+  const int k0 = kb * 32, krow = k0 + (lane & 31);
+  const float c = a.scale_log2e;
+  bf16x8 kf[4], vf[4];
+  if (active) {
+    load_lane_frags(qbase + D, D3, N, k0, lane, kf);
+    load_lane_frags(qbase + 2 * D, D3, N, k0, lane, vf);
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+  const int t_beg = a.causal ? kb : 0;                 // global query-tile bound: earlier queries never see this key block
+  for (int r0 = 0; r0 < N; r0 += CH) {
+    const int rows = min(CH, N - r0), ntc = (rows + 31) / 32;
+    __syncthreads();
+    stage_tile(qbase + (size_t)r0 * D3, D3, rows, ntc * 32, qtile, wave, lane);
+    stage_tile(dobase + (size_t)r0 * D, D, rows, ntc * 32, dotile, wave, lane);
+    for (int i = threadIdx.x; i < ntc * 32; i += 256) {
+      const size_t stat = ((size_t)b * a.H + hh) * N + min(r0 + i, N - 1);
+      lse_s[i] = a.lse2[stat];
+      delta_s[i] = a.delta[stat];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) continue;
+    for (int T = 0; T < ntc; ++T) {
+      const int Tg = r0 / 32 + T;
+      if (Tg < t_beg) continue;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, T, kk, lane), kf[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, T, kk, lane), vf[kk], dp, 0, 0, 0);
+      }
+      f32x16 pmat;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ql = 32 * T + 8 * u + 4 * (lane >> 5);        // row inside the staged chunk
+        const f32x4 lse4 = *(const f32x4*)(lse_s + ql);
+        const f32x4 del4 = *(const f32x4*)(delta_s + ql);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * u + i;
+          const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse4[i]));
+          float keep = 1.0f;
+          if constexpr (DROP) keep = attn_keep(a, blockIdx.x, min(r0 + ql + i, N - 1), min(krow, N - 1));
+          pmat[r] = pexp * keep;
+          s[r] = pexp * (dp[r] * keep - del4[i]);
+        }
+        if (r0 + 32 * T + 32 > N || k0 + 32 > N || (a.causal && Tg == kb)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * u + i, query = r0 + ql + i;
+            if (!(query < N && krow < N && (!a.causal || krow <= query))) { pmat[r] = 0.f; s[r] = 0.f; }
+          }
+        }
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 pf = acc_to_frag(pmat, sidx);
+        const bf16x8 dsf = acc_to_frag(s, sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dotile, T, sidx, dt, lane), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, T, sidx, dt, lane), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  float csum_k = 0.f, csum_v = 0.f;
+  __bf16* dbase = a.dqkv + (size_t)b * N * D3 + hh * DH;
+  store_rows_T_lds(dbase + D, D3, N, k0, lane, dk, a.scale, oimg, a.dbias ? &csum_k : nullptr);
+  store_rows_T_lds(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f, oimg, a.dbias ? &csum_v : nullptr);
+  if (a.dbias) {
+    atomicAdd(a.dbias + D + hh * DH + lane, csum_k);
+    atomicAdd(a.dbias + 2 * D + hh * DH + lane, csum_v);
+  }
+}
+
 int check(const AttnArgs& a) {
-  if (a.B <= 0 || a.N <= 0 || a.H <= 0 || a.N > MAX_N) return VITAMD_ERR_SHAPE;
+  if (a.B <= 0 || a.N <= 0 || a.H <= 0 || a.N > MAX_N_LONG) return VITAMD_ERR_SHAPE;
   return VITAMD_OK;
 }
 
@@ -523,6 +795,18 @@ extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B
   if (!qkv || !o || !lse2 || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
   const bool drop = a.drop_thresh != 0u;
   const int nkt = (N + 31) / 32, npad = nkt * 32;
+  if (N > MAX_N) {
+    const int lds = 2 * CH * 128;
+    const dim3 grid(B * H, (nkt + 3) / 4);
+    if (drop) {
+      if (int e = set_lds(attn_fwd_long_kernel<true>, lds)) return e;
+      hipLaunchKernelGGL(attn_fwd_long_kernel<true>, grid, dim3(256), lds, stream, a);
+    } else {
+      if (int e = set_lds(attn_fwd_long_kernel<false>, lds)) return e;
+      hipLaunchKernelGGL(attn_fwd_long_kernel<false>, grid, dim3(256), lds, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+  }
   if (nkt <= 8) {
     const int lds = 2 * npad * 128 + 4 * 4096;
     int e = VITAMD_OK;
@@ -552,6 +836,22 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
              0.125f * 1.4426950408889634f, 0.125f, 0u, 1.0f, 0u, 0u};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
+  if (N > MAX_N) {
+    const int ldsq = 2 * CH * 128 + 4 * 4096, ldsk = 2 * CH * 128 + 2 * CH * 4 + 4 * 4096;
+    const dim3 grid(B * H, ((N + 31) / 32 + 3) / 4);
+    if (a.drop_thresh) {
+      if (int e = set_lds(attn_bwd_dq_long_kernel<true>, ldsq)) return e;
+      if (int e = set_lds(attn_bwd_dkv_long_kernel<true>, ldsk)) return e;
+      hipLaunchKernelGGL(attn_bwd_dq_long_kernel<true>, grid, dim3(256), ldsq, stream, a);   // also writes delta
+      hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<true>, grid, dim3(256), ldsk, stream, a);
+    } else {
+      if (int e = set_lds(attn_bwd_dq_long_kernel<false>, ldsq)) return e;
+      if (int e = set_lds(attn_bwd_dkv_long_kernel<false>, ldsk)) return e;
+      hipLaunchKernelGGL(attn_bwd_dq_long_kernel<false>, grid, dim3(256), ldsq, stream, a);
+      hipLaunchKernelGGL(attn_bwd_dkv_long_kernel<false>, grid, dim3(256), ldsk, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+  }
   const int npad = (N + 31) / 32 * 32;
   const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
   if (a.drop_thresh) {
