@@ -79,6 +79,11 @@ int vitamd_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean,
 int vitamd_layernorm_bwd_dropout(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
                                  const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D,
                                  float dropout_p, unsigned long long seed, void* stream);
+/* Same backward with xhat read back from the forward's bf16 output y_bf16 (for this non-affine LayerNorm y IS xhat, and it is
+ * saved anyway as the operand of the following Linear's weight gradient) instead of recomputed from x: 14 instead of 16 B per
+ * element of an HBM-bound kernel; D in {256, 512, 768, 1024}; dropout_p = 0 for no mask on the bf16 copy. */
+int vitamd_layernorm_bwd_xhat(const void* dy_bf16, const void* y_bf16, const float* rstd, const float* g_res, float* g_out,
+                              void* g_bf16, float* colsum, int M, int D, float dropout_p, unsigned long long seed, void* stream);
 
 /* Affine LayerNorm (nn.LayerNorm weight/bias) for the `blocks.py` surface (blocks.py:43,48,179,184).
  * forward: y = bf16(LN(x) * gamma + beta).  backward: g_out = (g_res or 0) + dLN/dx; dgamma, dbeta are

@@ -250,6 +250,27 @@ def test_layernorm_fwd_bwd(hip, M, D):
     assert none is None and O.rel_l2(g2.cpu(), xr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("M,D", [(777, 768), (320, 512), (50, 1024), (5, 256)])
+def test_layernorm_bwd_xhat_mode(hip, M, D):
+    """LayerNorm backward reading xhat from the forward's bf16 output instead of recomputing it from fp32 x: the bf16 rounding of
+    xhat only enters the xhat * mean(dy * xhat) term, so the result must stay within 1e-3 of the recomputing kernel and of the
+    fp32 formula (it is ~2e-4 in practice); the bf16 copy and its column sums follow."""
+    from vitamd import ops
+    x = (randn((M, D), 71, 2.0) + 0.3).to(dev())
+    dy = r16(randn((M, D), 72)).to(dev(), BF16)
+    gres = randn((M, D), 73).to(dev())
+    _, y, mean, rstd = ops.layernorm_fwd(x)
+    c1, c2 = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    g_ref, gb_ref = ops.layernorm_bwd(dy, x, mean, rstd, g_res=gres, want_bf16=True, colsum=c1)
+    g, gb = ops.layernorm_bwd(dy, x, mean, rstd, g_res=gres, want_bf16=True, colsum=c2, xhat=y)
+    assert O.rel_l2(g.cpu(), g_ref.cpu()) < 1e-3
+    assert O.rel_l2(gb.float().cpu(), gb_ref.float().cpu()) < 5e-3          # bf16 roundings may flip the last bit
+    assert O.rel_l2(c2.cpu(), gb.float().sum(0).cpu()) < 1e-4
+    xr = x.cpu().clone().requires_grad_(True)
+    O.layer_norm(xr).backward(dy.float().cpu())
+    assert O.rel_l2(g.cpu(), xr.grad + gres.cpu()) < 1e-3
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _attn_ref(qkv, B, N, H, causal, d_o=None):
     t = qkv.view(B, N, 3 * H * 64).clone().requires_grad_(True)

@@ -1,5 +1,5 @@
-"""A/B on the whole training step: gelu' evaluated in the fc1 epilogue and stored (production) vs evaluated in the
-fc2-dgrad epilogue from the stored pre-activation.  Interleaved, medians."""
+"""A/B on the whole training step of the two dataflow choices made in vitamd/functions.py: gelu' stored by the fc1 epilogue vs
+evaluated in the fc2-dgrad epilogue; LayerNorm backward reading xhat from the saved bf16 LN output vs recomputing it from x."""
 import os, sys, time, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
@@ -17,9 +17,10 @@ def timed(n=5):
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 for _ in range(3): step()
-res = {True: [], False: []}
-for r in range(6):
-    for flag in (True, False):
-        F.GELU_STORED_GRAD = flag; res[flag].append(timed())
-print("stored gelu' (production): median %.2f ms/step  %s" % (statistics.median(res[True]), ["%.2f" % v for v in res[True]]))
-print("gelu' in backward        : median %.2f ms/step  %s" % (statistics.median(res[False]), ["%.2f" % v for v in res[False]]))
+cfgs = {"production": (True, True), "gelu' evaluated in backward": (False, True), "LN backward recomputes xhat from fp32 x": (True, False)}
+res = {k: [] for k in cfgs}
+for r in range(5):
+    for k, (gs, lx) in cfgs.items():
+        F.GELU_STORED_GRAD, F.LN_BWD_XHAT = gs, lx; res[k].append(timed())
+F.GELU_STORED_GRAD, F.LN_BWD_XHAT = True, True
+for k in cfgs: print("%-42s median %.2f ms/step  %s" % (k, statistics.median(res[k]), ["%.2f" % v for v in res[k]]))

@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256) void ln_fwd_generic(const float* __restrict__ 
   }
 }
 
-template <int NV>
+// XH: xhat is read back from the forward's bf16 output y (= LN(x) exactly for this non-affine LayerNorm, saved anyway as the
+// weight-gradient operand of the following Linear) through the `x` pointer, instead of being recomputed from the fp32 input:
+// 2 B instead of 4 B per element of an HBM-bound kernel (16 -> 14 B/elem), `mean` unused.  The bf16 rounding of xhat only
+// touches the xhat * mean(dy * xhat) term (|.| ~ 0.1 |dy|): ~2e-4 relative on g, far below the bf16 roundings around it.
+template <int NV, bool XH = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ g_res, float* __restrict__ g_out,
@@ -90,17 +94,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
   for (int j = 0; j < NV; ++j) cs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * ROWS_PER_BLOCK) {
     const size_t base = (size_t)row * D;
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = XH ? 0.f : mean[row], rs = rstd[row];
     f32x4 d[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const u32x2 a = *(const u32x2*)(dy + base + j * 256 + lane * 4);
       d[j] = (f32x4){bf16lo(a[0]), bf16hi(a[0]), bf16lo(a[1]), bf16hi(a[1])};
-      const f32x4 xv = *(const f32x4*)(x + base + j * 256 + lane * 4);
+      if constexpr (XH) {
+        const u32x2 yb = *(const u32x2*)((const __bf16*)x + base + j * 256 + lane * 4);
+        xh[j] = (f32x4){bf16lo(yb[0]), bf16hi(yb[0]), bf16lo(yb[1]), bf16hi(yb[1])};
+      } else {
+        const f32x4 xv = *(const f32x4*)(x + base + j * 256 + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xh[j][c] = (xv[c] - mu) * rs;
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        xh[j][c] = (xv[c] - mu) * rs;
         s1 += d[j][c];
         s2 += d[j][c] * xh[j][c];
       }
@@ -236,4 +246,29 @@ extern "C" int vitamd_layernorm_bwd_dropout(const void* dy_bf16, const float* x,
                                             const float* g_res, float* g_out, void* g_bf16, float* colsum, int M, int D,
                                             float dropout_p, unsigned long long seed, void* stream) {
   return ln_bwd_launch(dy_bf16, x, mean, rstd, g_res, g_out, g_bf16, colsum, M, D, dropout_p, seed, stream);
+}
+
+// LayerNorm backward with xhat taken from the forward's bf16 output (see ln_bwd_kernel<NV, true>): D in {256, 512, 768, 1024}.
+extern "C" int vitamd_layernorm_bwd_xhat(const void* dy_bf16, const void* y_bf16, const float* rstd, const float* g_res, float* g_out,
+                                         void* g_bf16, float* colsum, int M, int D, float dropout_p, unsigned long long seed,
+                                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M <= 0 || (D != 256 && D != 512 && D != 768 && D != 1024)) return VITAMD_ERR_SHAPE;
+  if (!dy_bf16 || !y_bf16 || !rstd || !g_out) return VITAMD_ERR_ARG;
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return VITAMD_ERR_ARG;
+  unsigned dthresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  if (dropout_p > 0.f && dthresh == 0u) dthresh = 1u;
+  const float dscale = 1.0f / (1.0f - dropout_p);
+  const unsigned slo = (unsigned)seed, shi = (unsigned)(seed >> 32);
+  const __bf16* dy = (const __bf16*)dy_bf16;
+  const float* yx = (const float*)y_bf16;        // the kernel reinterprets it (XH = true)
+  __bf16* gb = (__bf16*)g_bf16;
+  const int grid = grid_for(M);
+#define LN_BWDX(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(grid), dim3(256), 0, stream, dy, yx, (const float*)nullptr, rstd, g_res, g_out, gb, colsum, M, dthresh, dscale, slo, shi)
+  if (D == 256) { LN_BWDX(1); }
+  else if (D == 512) { LN_BWDX(2); }
+  else if (D == 768) { LN_BWDX(3); }
+  else { LN_BWDX(4); }
+#undef LN_BWDX
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

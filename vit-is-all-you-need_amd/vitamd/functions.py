@@ -103,6 +103,7 @@ class WeightCache:
 WEIGHTS = WeightCache()
 
 
+LN_BWD_XHAT = True        # A/B knob (tools/ab_gelu.py): LayerNorm backward reads xhat from the saved bf16 LN output instead of recomputing it from fp32 x
 GELU_STORED_GRAD = True   # A/B knob (tools/ab_gelu.py); False = keep the pre-activation and evaluate gelu' in the backward
 
 
@@ -234,12 +235,13 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
     dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DMUL if GELU_STORED_GRAD else ops.EPI_DGELU, aux=pre, colsum=db1)   # dgrad fc2 . gelu'
     on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False), dpre, bln, dW1)
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
-    g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True)
+    g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True, xhat=bln if LN_BWD_XHAT else None)
     # ---- attention
     dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=dbqkv, dropout=drop[:2])   # also adds the QKV bias gradient
     on_side(lambda: ops.gemm_tn(dqkv, a, dWqkv, accumulate=False), dqkv, a, dWqkv)
     da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
-    g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum, dropout=emit_dropout)
+    g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum, dropout=emit_dropout,
+                                xhat=a if LN_BWD_XHAT else None)
     return g0, g0b
 
 

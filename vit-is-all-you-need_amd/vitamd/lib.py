@@ -33,6 +33,7 @@ SIGNATURES = {
     "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],
+    "vitamd_layernorm_bwd_xhat": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],
     "vitamd_linear_dropout_resid_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P],
     "vitamd_cast_f32_bf16_dropout": [_P, _P, _L, _F, _U64, _P],
     "vitamd_cast_f32_bf16": [_P, _P, _L, _P],

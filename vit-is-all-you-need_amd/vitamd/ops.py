@@ -111,15 +111,23 @@ def layernorm_fwd(x, addend=None):
     return (x_out if addend is not None else x), y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, g_res=None, want_bf16=False, colsum=None, dropout=(0.0, 0)):
+def layernorm_bwd(dy, x, mean, rstd, g_res=None, want_bf16=False, colsum=None, dropout=(0.0, 0), xhat=None):
     """g = (g_res or 0) + LN'(dy); returns (g fp32, bf16(g) or None).  dropout=(p, seed): the bf16 copy
-    also gets that dropout mask (it is then the gradient of a dropped-out Linear output)."""
+    also gets that dropout mask (it is then the gradient of a dropped-out Linear output).
+    xhat: the forward's bf16 output (= xhat for this non-affine LayerNorm); given, and D in {256,512,768,1024}, the kernel reads
+    it instead of recomputing xhat from the fp32 x (2 B instead of 4 B per element of an HBM-bound kernel)."""
     _need(dy, BF16, "dy", 2); _need(x, F32, "x", 2)
     M, D = x.shape
     g = torch.empty_like(x)
     gb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
     if g_res is not None:
         _need(g_res, F32, "g_res", 2)
+    if xhat is not None and D in (256, 512, 768, 1024):
+        _need(xhat, BF16, "xhat", 2)
+        code = _L().vitamd_layernorm_bwd_xhat(_p(dy), _p(xhat), _p(rstd), _p(g_res), _p(g), _p(gb), _p(colsum), M, D,
+                                              float(dropout[0]), int(dropout[1]), _stream())
+        _lib.check(code, f"layernorm_bwd_xhat[M={M},D={D}]")
+        return g, gb
     code = _L().vitamd_layernorm_bwd_dropout(_p(dy), _p(x), _p(mean), _p(rstd), _p(g_res), _p(g), _p(gb), _p(colsum), M, D,
                                              float(dropout[0]), int(dropout[1]), _stream())
     _lib.check(code, f"layernorm_bwd[M={M},D={D}]")
