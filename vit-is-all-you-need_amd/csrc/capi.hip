@@ -6,8 +6,13 @@
 extern "C" int vitamd_abi_version(void) { return 4; }
 
 int g_vitamd_debug = 0;
-// timing-only ablation knob for tools/ablate_*.py (bit 0: skip GELU math, bit 1: skip the second store,
-// bit 2: skip the epilogue loads).  Results are wrong when non-zero.  Not part of the public header.
+// Diagnostics knob for the A/B tools (tools/ab_dbg.py, tools/ablate_*.py); process-global, 0 in production, NOT in the public
+// header.  Bits marked (!) make results wrong (timing only).
+//   NT GEMM : 0 skip gelu math(!)   1 skip 2nd GELU store(!)   2 skip residual load(!)   3 plain (temporal) output stores
+//             4 tail split for every GEMM   5 plain tile order   7 no fc2-forward tail split   8-15 stagger unit in ~us (255 = off)
+//             16 no output stores(!)   17 one K-tile only(!)   19 no 320-row tiles   20-23 stagger phases   24 stagger map
+//             29 stage through VGPRs instead of LDS-DMA
+//   TN GEMM : 6 16x16x32 form   25 256x384-tile kernel (gemm_tn_wide.hip)   26-28: 1 no MFMA(!) 2 no loads(!) 3 no LDS reads(!) 5 LDS-DMA staging
 extern "C" int vitamd_set_debug(int bits) { g_vitamd_debug = bits; return 0; }
 
 extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
