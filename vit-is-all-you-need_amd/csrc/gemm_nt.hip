@@ -1152,21 +1152,24 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   // the isolated N = 768 GEMMs, but -0.5 ms on the whole step (tools/ab_step.py) because the weight-
   // gradient GEMMs on the side stream already fill those tails in backward.
   constexpr int CUS = 256;
-  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const bool tall = p.tile == 0 && prefer_tall(p);
+  const int bm = tall ? 320 : 256;
+  const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + 255) / 256;
   const long big_tiles = (long)tiles_m * tiles_n;
   const long rem = big_tiles % CUS;
-  // on for the fc2 forward GEMM only (fp32 residual epilogue, N = 768: 591 tiles = 2.31 rounds): single-stream profile
-  // 233 + 64 us split vs 323 us unsplit, whole-step A/B -0.2 ms; for every other GEMM the split LOSES (+0.9 ms with
-  // bit 4, which forces it everywhere): their tails are filled by the weight-gradient GEMMs of the side stream.
-  // vitamd_set_debug bit 7 turns it off, bit 4 forces it for every GEMM.
-  const bool split_on = ((p.dbg & 16) != 0 || (p.epi == EPI_RESID_F32 && !(p.dbg & 128))) && !(p.tile == 0 && prefer_tall(p));
+  // Tail split: the last, mostly empty round of big tiles is re-cut into 128x128 tiles.  Only ever paid for the fc2 FORWARD GEMM
+  // on 256-row tiles (591 tiles = 2.31 rounds; -0.2 ms/step), which the 320-row tile has since replaced (474 tiles = 1.85 rounds:
+  // no split).  Everywhere else it loses on the whole step: +0.9 ms forced on every GEMM (bit 4) because the weight-gradient GEMMs
+  // of the side stream already fill the backward tails, +0.2 ms on fc1+GELU at 7.4 rounds of 320-row tiles (the 128x128 kernel's
+  // direct-store GELU epilogue costs more than the 0.6 idle round).  vitamd_set_debug bit 7 turns it off, bit 4 forces it.
+  const bool split_on = (p.dbg & 16) != 0 || (!(p.dbg & 128) && p.epi == EPI_RESID_F32 && !tall);
   if (p.tile == 0 && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
     const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
-    const int rows_a = panels_a * 256;
+    const int rows_a = panels_a * bm;
     if (panels_a > 0 && rows_a < p.M) {
       GemmNtArgs a = p, b = p;
       a.M = rows_a;
-      a.tile = 2;
+      a.tile = tall ? 0 : 2;                                          // (auto picks the 320-row form again for the head part)
       const size_t esz_out = (p.epi == EPI_RESID_F32 || p.epi == EPI_F32) ? 4 : 2;
       b.M = p.M - rows_a;
       b.A = (const char*)p.A + (size_t)rows_a * p.K * 2;
