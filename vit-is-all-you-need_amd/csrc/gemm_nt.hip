@@ -1145,12 +1145,8 @@ static int dispatch_epi(const GemmNtArgs& p, hipStream_t stream) {
 int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
   if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
-  // Tail split.  One 256x256 workgroup per CU means a launch runs in
-  // whole rounds of 256 tiles; a last round that is mostly empty (591 tiles = 2.31 rounds at N = 768)
-  // idles most of the chip for a full tile time.  With the split, the big kernel takes only the
-  // M-panels that fill whole rounds and the remaining rows go to the 128x128 kernel.  Measured: +5 % on
-  // the isolated N = 768 GEMMs, but -0.5 ms on the whole step (tools/ab_step.py) because the weight-
-  // gradient GEMMs on the side stream already fill those tails in backward.
+  // One big-tile workgroup per CU means a launch runs in whole rounds of 256 tiles; a last round that is mostly empty idles most of
+  // the chip for a full tile time.  Two remedies live here: the tile height (prefer_tall) and the tail split below.
   constexpr int CUS = 256;
   const bool tall = p.tile == 0 && prefer_tall(p);
   const int bm = tall ? 320 : 256;
