@@ -101,7 +101,7 @@ def pmc_traffic():
 
 def cpu_baseline():
     """The CPU oracle (fp32 restatement of the reference, oracle/vit_oracle.py) timed on this
-    host's cores on a bounded sample: 2 forward+backward iterations of batch 16 after one warm-up."""
+    host's cores on a bounded sample: 5 forward+backward iterations of batch 16 after one warm-up (~10 s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vit_oracle as O
     import weights as W
@@ -110,7 +110,7 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     cfg = O.OracleViTConfig.preset(224, 3, 16, "B", 1)
     sd = W.classifier_state(0, 3, 16, cfg.n_patches, 1, cfg.n_layers, cfg.n_embd, 1000)
-    bs, iters = 16, 2
+    bs, iters = 16, 5
     images = W.normal(0, "images", (bs, 3, 224, 224))
     labels = W.randint(0, "labels", (bs,), 1000)
     O.classifier_loss_and_grads(images[:4], labels[:4], sd, cfg)
