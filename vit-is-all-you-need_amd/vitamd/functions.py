@@ -103,6 +103,20 @@ class WeightCache:
 WEIGHTS = WeightCache()
 
 
+TN_TARGET_WGS = 180       # workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU)
+
+
+def _tn_splits(dW):
+    """Split-K factor for a weight-gradient GEMM that runs on the side stream BESIDE the input-gradient chain: a little under one
+    workgroup per CU (180 of 256) - fewer, longer workgroups write fewer fp32 partial tiles for the reduce pass, and the CUs they
+    leave free are taken by the main stream's kernels anyway.  Whole-step A/B (tools/ab_splits.py): 5 splits instead of 7 on the
+    36-tile GEMMs of ViT-B: -0.2 ms/step; 3 or fewer lose (36.9 ms at 3, 46 ms at 2)."""
+    if not TN_TARGET_WGS:
+        return 0
+    ntile = ((dW.shape[0] + 255) // 256) * ((dW.shape[1] + 255) // 256)
+    return max(1, round(TN_TARGET_WGS / ntile))
+
+
 LN_BWD_XHAT = True        # A/B knob (tools/ab_gelu.py): LayerNorm backward reads xhat from the saved bf16 LN output instead of recomputing it from fp32 x
 GELU_STORED_GRAD = True   # A/B knob (tools/ab_gelu.py); False = keep the pre-activation and evaluate gelu' in the backward
 
@@ -228,17 +242,17 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
         dy2 = ops.cast_bf16_dropout(g2, drop[2:]) if drop[2] > 0 else ops.cast_bf16(g2)
     # ---- MLP
     def wgrad_fc2():
-        ops.gemm_tn(dy2, h, dW2, accumulate=False)
+        ops.gemm_tn(dy2, h, dW2, accumulate=False, splits=_tn_splits(dW2))
         if not have_db2:
             ops.colsum(dy2, db2)
     on_side(wgrad_fc2, dy2, h, dW2, db2)
     dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DMUL if GELU_STORED_GRAD else ops.EPI_DGELU, aux=pre, colsum=db1)   # dgrad fc2 . gelu'
-    on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False), dpre, bln, dW1)
+    on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1)), dpre, bln, dW1)
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True, xhat=bln if LN_BWD_XHAT else None)
     # ---- attention
     dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=dbqkv, dropout=drop[:2])   # also adds the QKV bias gradient
-    on_side(lambda: ops.gemm_tn(dqkv, a, dWqkv, accumulate=False), dqkv, a, dWqkv)
+    on_side(lambda: ops.gemm_tn(dqkv, a, dWqkv, accumulate=False, splits=_tn_splits(dWqkv)), dqkv, a, dWqkv)
     da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
     g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum, dropout=emit_dropout,
                                 xhat=a if LN_BWD_XHAT else None)
