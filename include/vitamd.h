@@ -108,6 +108,11 @@ int vitamd_layernorm_affine_bwd_f32(const float* dy, const float* x, const float
  * hash of (seed, batch, head, query, key), so the backward call regenerates it from the same seed. */
 int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal,
                          float dropout_p, unsigned long long seed, void* stream);
+/* Forward fused with the residual add that follows it in the layer (transformer.py:44 `x = x + attn(LN(x))`):
+ * resid_out fp32 [B*N, H*64] = resid_in + o (o as rounded to bf16), written by the same workgroup that produces o, so the next
+ * LayerNorm reads the stream once (6 instead of 12 B per element).  N <= 256 (the register-resident-softmax kernel). */
+int vitamd_attention_fwd_resid(const void* qkv, void* o, float* lse2, const float* resid_in, float* resid_out, int B, int N, int H,
+                               int head_dim, int causal, float dropout_p, unsigned long long seed, void* stream);
 /* dqkv bf16 [B,N,3,H,64]; delta fp32 [B,H,N] is scratch written by the call; dbias (may be NULL) fp32
  * [3*H*64]: the column sums of dqkv (= gradient of the QKV bias, transformer.py:21) are ADDED to it. */
 int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, const void* d_o, void* dqkv,

@@ -330,6 +330,21 @@ def test_attention_long_sequences(hip, B, N, H, causal):
         assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 1.2e-2, name
 
 
+@pytest.mark.parametrize("B,N,H,causal", [(2, 197, 3, False), (1, 256, 2, True), (3, 37, 2, False), (2, 5, 1, False)])
+def test_attention_fwd_fused_residual(hip, B, N, H, causal):
+    """Forward with the layer's residual add in its epilogue (N <= 256): o and lse identical to the plain kernel, and
+    x1 = x0 + o bit-exact against the same sum done by torch (fp32 add of the bf16-rounded o)."""
+    from vitamd import ops, lib
+    qkv = r16(randn((B * N, 3 * H * 64), 231 + N, 1.5)).to(dev(), BF16)
+    x0 = randn((B * N, H * 64), 232 + N, 2.0).to(dev())
+    o_ref, lse_ref = ops.attention_fwd(qkv, B, N, H, causal)
+    o, lse, x1 = ops.attention_fwd(qkv, B, N, H, causal, resid=x0)
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    assert torch.equal(x1, x0 + o_ref.float())
+    with pytest.raises(lib.VitamdError):
+        ops.attention_fwd(torch.zeros((300, 192), device=dev(), dtype=BF16), 1, 300, 1, False, resid=torch.zeros((300, 64), device=dev()))
+
+
 def test_attention_softmax_spike(hip):
     """A key that dominates late in the sequence forces the online-softmax rescale branch."""
     from vitamd import ops

@@ -17,10 +17,11 @@ def timed(n=5):
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 for _ in range(3): step()
-cfgs = {"production": (True, True), "gelu' evaluated in backward": (False, True), "LN backward recomputes xhat from fp32 x": (True, False)}
+cfgs = {"production": (True, True, False), "gelu' evaluated in backward": (False, True, False), "LN backward recomputes xhat from fp32 x": (True, False, False),
+        "residual add fused into the attention forward": (True, True, True)}
 res = {k: [] for k in cfgs}
 for r in range(5):
-    for k, (gs, lx) in cfgs.items():
-        F.GELU_STORED_GRAD, F.LN_BWD_XHAT = gs, lx; res[k].append(timed())
-F.GELU_STORED_GRAD, F.LN_BWD_XHAT = True, True
-for k in cfgs: print("%-42s median %.2f ms/step  %s" % (k, statistics.median(res[k]), ["%.2f" % v for v in res[k]]))
+    for k, (gs, lx, ar) in cfgs.items():
+        F.GELU_STORED_GRAD, F.LN_BWD_XHAT, F.ATTN_FUSED_RESID = gs, lx, ar; res[k].append(timed())
+F.GELU_STORED_GRAD, F.LN_BWD_XHAT, F.ATTN_FUSED_RESID = True, True, False
+for k in cfgs: print("%-46s median %.2f ms/step  %s" % (k, statistics.median(res[k]), ["%.2f" % v for v in res[k]]))

@@ -135,6 +135,43 @@ __device__ __forceinline__ void store_rows_T_lds(__bf16* __restrict__ g, int ld,
   }
 }
 
+// store_rows_T_lds + the residual add of the fp32 stream: xo[row][d] = xi[row][d] + bf16(acc) for the same 32 rows x 64 columns
+__device__ __forceinline__ void store_rows_T_lds_resid(__bf16* __restrict__ g, int ld, int N, int r0, int lane, const f32x16 (&acc)[2],
+                                                       float scale, char* img, const float* __restrict__ xi, float* __restrict__ xo, int ldx) {
+  const int rr = lane & 31, h = lane >> 5;
+  // residual loads first: their latency overlaps the LDS round trip
+  f32x4 r[4][2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (lane >> 3) + 8 * it, pc = lane & 7;
+    const float* px = xi + (size_t)min(r0 + row, N - 1) * ldx + 8 * (pc ^ (row & 7));
+    r[it][0] = *(const f32x4*)px;
+    r[it][1] = *(const f32x4*)(px + 4);
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      u32x2 o = {pack_bf16x2(acc[dt][4 * u] * scale, acc[dt][4 * u + 1] * scale),
+                 pack_bf16x2(acc[dt][4 * u + 2] * scale, acc[dt][4 * u + 3] * scale)};
+      *(u32x2*)(img + rr * 128 + (((4 * dt + u) ^ (rr & 7)) << 4) + h * 8) = o;
+    }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (lane >> 3) + 8 * it, pc = lane & 7;
+    const u32x4 v = *(const u32x4*)(img + row * 128 + pc * 16);
+    if (r0 + row < N) {
+      const int col = 8 * (pc ^ (row & 7));
+      *(u32x4*)(g + (size_t)(r0 + row) * ld + col) = v;
+      f32x4 o0 = {r[it][0][0] + bf16lo(v[0]), r[it][0][1] + bf16hi(v[0]), r[it][0][2] + bf16lo(v[1]), r[it][0][3] + bf16hi(v[1])};
+      f32x4 o1 = {r[it][1][0] + bf16lo(v[2]), r[it][1][1] + bf16hi(v[2]), r[it][1][2] + bf16lo(v[3]), r[it][1][3] + bf16hi(v[3])};
+      float* po = xo + (size_t)(r0 + row) * ldx + col;
+      *(f32x4*)po = o0;
+      *(f32x4*)(po + 4) = o1;
+    }
+  }
+}
+
 struct AttnArgs {
   const __bf16* qkv;   // [B, N, 3, H, 64]
   __bf16* o;           // fwd out / bwd in  [B, N, H*64]
@@ -151,6 +188,10 @@ struct AttnArgs {
   unsigned drop_thresh;
   float drop_scale;
   unsigned seed_lo, seed_hi;
+  // forward only, optional: fp32 residual stream [B*N, H*64]; with both set the kernel also writes resid_out = resid_in + bf16(o)
+  // (transformer.py:44 `x = x + attn(...)`), so the LayerNorm that follows reads x once instead of x and o and writing x
+  const float* resid_in;
+  float* resid_out;
 };
 
 // keep-scale of probability (b, head, query, key): 1/(1-p) or 0
@@ -237,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 // The whole score row of a query fits in registers (NKT tiles x 16 fp32), so there is no online
 // rescaling: S for every key tile, one row maximum, exp2, then P.V.  Per element the VALU work is
 // fma + v_exp + add + cvt (the kernel is VALU-bound at dh = 64, not MFMA-bound).
-template <int NKT, bool DROP>
+template <int NKT, bool DROP, bool RES = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -309,7 +350,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    store_rows_T_lds(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg);
+    if constexpr (RES)
+      store_rows_T_lds_resid(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg, a.resid_in + (size_t)b * N * D + hh * DH,
+                             a.resid_out + (size_t)b * N * D + hh * DH, D);
+    else
+      store_rows_T_lds(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg);
     if (lane < 32 && qrow < N) a.lse2[((size_t)b * a.H + hh) * N + qrow] = mc + log2f(l);
   }
 }
@@ -780,17 +825,38 @@ static bool attn_dropout(AttnArgs& a, float p, unsigned long long seed) {
 
 template <int K, bool DROP>
 static int launch_fwd_small(const AttnArgs& a, int lds, hipStream_t stream) {
+  if (a.resid_in) {
+    if (int e = set_lds((attn_fwd_small_kernel<K, DROP, true>), lds)) return e;
+    hipLaunchKernelGGL((attn_fwd_small_kernel<K, DROP, true>), dim3(a.B * a.H), dim3(256), lds, stream, a);
+    return VITAMD_OK;
+  }
   if (int e = set_lds(attn_fwd_small_kernel<K, DROP>, lds)) return e;
   hipLaunchKernelGGL((attn_fwd_small_kernel<K, DROP>), dim3(a.B * a.H), dim3(256), lds, stream, a);
   return VITAMD_OK;
 }
 
+static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float* resid_in, float* resid_out, int B, int N, int H,
+                              int head_dim, int causal, float dropout_p, unsigned long long seed, void* stream_);
+
 extern "C" int vitamd_attention_fwd(const void* qkv, void* o, float* lse2, int B, int N, int H, int head_dim, int causal,
                                     float dropout_p, unsigned long long seed, void* stream_) {
+  return attention_fwd_impl(qkv, o, lse2, nullptr, nullptr, B, N, H, head_dim, causal, dropout_p, seed, stream_);
+}
+
+// forward + the residual add that follows it in the layer: resid_out = resid_in + o  (fp32 [B*N, H*64]); N <= 256 only
+extern "C" int vitamd_attention_fwd_resid(const void* qkv, void* o, float* lse2, const float* resid_in, float* resid_out, int B, int N,
+                                          int H, int head_dim, int causal, float dropout_p, unsigned long long seed, void* stream_) {
+  if (!resid_in || !resid_out) return VITAMD_ERR_ARG;
+  if (N > 256) return VITAMD_ERR_SHAPE;
+  return attention_fwd_impl(qkv, o, lse2, resid_in, resid_out, B, N, H, head_dim, causal, dropout_p, seed, stream_);
+}
+
+static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float* resid_in, float* resid_out, int B, int N, int H,
+                              int head_dim, int causal, float dropout_p, unsigned long long seed, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
   AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f,
-             0u, 1.0f, 0u, 0u};
+             0u, 1.0f, 0u, 0u, resid_in, resid_out};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2 || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
   const bool drop = a.drop_thresh != 0u;
@@ -833,7 +899,7 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
   hipStream_t stream = (hipStream_t)stream_;
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
   AttnArgs a{(const __bf16*)qkv, (__bf16*)o, (float*)lse2, (const __bf16*)d_o, (__bf16*)dqkv, delta, dbias, B, N, H, causal,
-             0.125f * 1.4426950408889634f, 0.125f, 0u, 1.0f, 0u, 0u};
+             0.125f * 1.4426950408889634f, 0.125f, 0u, 1.0f, 0u, 0u, nullptr, nullptr};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
   if (N > MAX_N) {

@@ -103,6 +103,7 @@ class WeightCache:
 WEIGHTS = WeightCache()
 
 
+ATTN_FUSED_RESID = False  # A/B knob: x1 = x0 + attention written by the attention forward kernel (N <= 256): correct, measured EQUAL (34.47 vs 34.43 ms)
 TN_TARGET_WGS = 180       # workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU)
 
 
@@ -143,8 +144,14 @@ def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad, p_
     w2_b, _ = WEIGHTS.get(w2, need_grad)
     _, a, mean1, rstd1 = ops.layernorm_fwd(x0)                                   # LN1            transformer.py:43
     qkv = ops.gemm_nt(a, wqkv_b, ops.EPI_BIAS_BF16, bias=bqkv)                   # fused QKV      transformer.py:27
-    o, lse = ops.attention_fwd(qkv, B, N, H, causal, dropout=drop[:2])           # SDPA           transformer.py:28-29
-    x1, bln, mean2, rstd2 = ops.layernorm_fwd(x0, addend=o)                      # residual + LN2 transformer.py:43-44
+    if ATTN_FUSED_RESID and N <= ops.ATTN_RESID_MAX_N:
+        # SDPA (transformer.py:28-29) with the residual add of transformer.py:44 in its epilogue: the LayerNorm below then reads the
+        # fp32 stream once (6 B/element) instead of reading x0 and o and writing x1 (12 B/element)
+        o, lse, x1 = ops.attention_fwd(qkv, B, N, H, causal, dropout=drop[:2], resid=x0)
+        _, bln, mean2, rstd2 = ops.layernorm_fwd(x1)                             # LN2            transformer.py:43
+    else:
+        o, lse = ops.attention_fwd(qkv, B, N, H, causal, dropout=drop[:2])       # SDPA           transformer.py:28-29
+        x1, bln, mean2, rstd2 = ops.layernorm_fwd(x0, addend=o)                  # residual + LN2 transformer.py:43-44
     # fc1 + GELU (transformer.py:37-38); `pre` holds bf16(gelu'(fc1 out)) for the backward - the derivative is evaluated
     # here, where its exp is shared with the erf and the VALU work hides under the output stores (-85 us per layer in dgrad fc2)
     pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU_DG if GELU_STORED_GRAD else ops.EPI_GELU, bias=b1)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "vitamd_layernorm_affine_fwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "vitamd_layernorm_affine_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vitamd_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
+    "vitamd_attention_fwd_resid": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],
     "vitamd_layernorm_bwd_xhat": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],

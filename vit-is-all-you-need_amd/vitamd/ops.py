@@ -182,15 +182,28 @@ def layernorm_affine_bwd_f32(dy, x, mean, rstd, gamma, dgamma, dbeta):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention_fwd(qkv, B, N, H, causal=False, dropout=(0.0, 0)):
+ATTN_RESID_MAX_N = 256    # the fused residual add lives in the register-resident-softmax forward kernel
+
+
+def attention_fwd(qkv, B, N, H, causal=False, dropout=(0.0, 0), resid=None):
     """qkv bf16 [B*N, 3*H*64] (packed (qkv, head, dh)) -> o bf16 [B*N, H*64], lse2 fp32 [B,H,N].
-    dropout=(p, seed): dropout on the softmax probabilities."""
+    dropout=(p, seed): dropout on the softmax probabilities.
+    resid (fp32 [B*N, H*64], N <= 256): also returns x1 = resid + o, written by the attention kernel itself -> (o, lse2, x1)."""
     _need(qkv, BF16, "qkv", 2)
     D = H * 64
     if tuple(qkv.shape) != (B * N, 3 * D):
         raise _lib.VitamdError("attention_fwd: qkv must be [B*N, 3*H*64] (head_dim 64 only)")
     o = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+    if resid is not None:
+        _need(resid, F32, "resid", 2)
+        if tuple(resid.shape) != (B * N, D):
+            raise _lib.VitamdError("attention_fwd: resid must be [B*N, H*64]")
+        x1 = torch.empty_like(resid)
+        code = _L().vitamd_attention_fwd_resid(_p(qkv), _p(o), _p(lse), _p(resid), _p(x1), B, N, H, 64, int(causal), float(dropout[0]),
+                                               int(dropout[1]), _stream())
+        _lib.check(code, f"attention_fwd_resid[B={B},N={N},H={H}]")
+        return o, lse, x1
     code = _L().vitamd_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, H, 64, int(causal), float(dropout[0]), int(dropout[1]), _stream())
     _lib.check(code, f"attention_fwd[B={B},N={N},H={H}]")
     return o, lse
