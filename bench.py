@@ -80,7 +80,7 @@ def kernel_roofline(dev):
             "traffic_detail": pmc_traffic(), "per_shape_tflops": detail}
 
 
-PMC_PROFILE = os.path.join("profiles", "r01", "k_final_pmc_hbm_traffic.json")
+PMC_PROFILE = os.path.join("profiles", "r01", "m_final_pmc_hbm_traffic.json")
 
 
 def pmc_traffic():

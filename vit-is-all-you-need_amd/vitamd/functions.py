@@ -112,7 +112,7 @@ def _tn_splits(dW):
     workgroup per CU (180 of 256) - fewer, longer workgroups write fewer fp32 partial tiles for the reduce pass, and the CUs they
     leave free are taken by the main stream's kernels anyway.  Whole-step A/B (tools/ab_splits.py): 5 splits instead of 7 on the
     36-tile GEMMs of ViT-B: -0.2 ms/step; 3 or fewer lose (36.9 ms at 3, 46 ms at 2)."""
-    if not TN_TARGET_WGS:
+    if not TN_TARGET_WGS or not SIDE.enabled:      # alone on the chip (no side stream) the kernel's own rule - every CU - is right
         return 0
     ntile = ((dW.shape[0] + 255) // 256) * ((dW.shape[1] + 255) // 256)
     return max(1, round(TN_TARGET_WGS / ntile))
