@@ -122,6 +122,31 @@ def cpu_baseline():
             "sample": f"{iters} x (batch {bs} ViT-B/16 224 fp32 forward+loss+backward), CPU oracle, {dt:.1f} s"}
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, script, script_args, env=None, capture=False):
+    """Start `n` fresh rank processes of `script` on this node (one per GPU) through torch.distributed.run and relay their
+    output; returns the launcher's exit code.  Called by a parent that has NOT touched the GPU: the ranks are new child
+    processes (never an exec of an initialised one), rendezvous on 127.0.0.1."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script, *script_args]
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.setdefault("OMP_NUM_THREADS", "4")
+    if capture:                                     # tests: (exit code, everything the ranks printed)
+        r = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return r.returncode, r.stdout
+    return subprocess.run(cmd, env=e).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,9 +156,15 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this parent only launches the N ranks (no GPU call happens in it) and exits with their code
+        sys.exit(spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to mislabel the result")
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -185,6 +216,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+    dist_info = {"world_size": 1, "backend": backend, "devices": [dev.index]}
+    if world > 1:
+        devs = [None] * world
+        dist.all_gather_object(devs, dev.index)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": devs}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -197,7 +233,7 @@ def main():
                                    "configs[2] at 8 GPUs), random-init weights, 197 tokens, 79.44 M params",
                        "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}"},
             "model_flops_frac_of_peak": round(value / world * GFLOP_PER_IMAGE / 1e3 / PEAK_BF16_TFLOPS, 4),
-            "final_loss": round(loss_val, 4),
+            "final_loss": round(loss_val, 4), "dist": dist_info,
         }
         if not args.no_roofline:
             out["roofline"] = kernel_roofline(dev)

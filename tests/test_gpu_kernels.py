@@ -175,7 +175,7 @@ def test_gemm_tn_exact_integers(hip, R, P, Q, splits):
     assert torch.equal(out.cpu(), l.t() @ r)
 
 
-@pytest.mark.parametrize("dbg_bits", [64, 5 << 26])
+@pytest.mark.parametrize("dbg_bits", [64, 5 << 26, 6 << 26, 7 << 26])
 @pytest.mark.parametrize("R,P,Q", [(1000, 256, 256), (4133, 768, 512), (300, 200, 136)])
 def test_gemm_tn_alternative_kernels_exact_integers(hip, R, P, Q, dbg_bits):
     """The measured alternatives of the weight-gradient GEMM kept behind vitamd_set_debug: bit 6 = mfma_f32_16x16x32 form,

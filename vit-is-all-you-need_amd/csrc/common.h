@@ -50,6 +50,30 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, si
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
 }
 
+// ---- LDS-DMA that hipcc does not see (the ping-pong GEMM main loops) -------------------------------------------------------
+// hipcc (ROCm 7.2) models an LDS-DMA builtin as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the next ds_read
+// of the same __shared__ array - which drains a pipeline built on COUNTED waits.  Issued from inline asm the loads are invisible
+// to that bookkeeping: the kernel counts them by hand (s_waitcnt vmcnt(N) + s_barrier before any read of the landed bytes;
+// cdna_hip_programming.md section 5.7 item 1) and drains them with vmcnt(0) before LDS is reused or the wave ends.
+typedef __attribute__((ext_vector_type(4))) unsigned int srd_t;     // the four descriptor dwords, held in SGPRs
+__device__ __forceinline__ srd_t make_srd(const void* base, size_t bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  srd_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);   // base[47:32], stride 0
+  r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);                 // num_records: range check, out-of-range lanes write zeros
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const void*)p; }
+// 16 B per lane from srd[voff + soff] to LDS byte address lds_dst (wave-uniform) + 16*lane.  M0 is saved and restored inside the
+// statement (compiler-reserved); s_nop: SGPR/M0 write -> VMEM read wait states.
+__device__ __forceinline__ void asm_glds16(srd_t srd, unsigned lds_dst, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
 // erf with |abs err| < 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp, one v_rcp, 5 fma.
 // Outputs are rounded to bf16 (2^-9 relative) so this is exact for our purposes.
 __device__ __forceinline__ float fast_erf(float x) {

@@ -18,6 +18,7 @@
 //   gemm_nt_deep_kernel     256x256, BK=32, 3..5-stage ring                              (tile=3..5, much slower on the whole step)
 // Epilogues: gemm_epilogue_rows (LDS-transposed, row-major 16-B accesses; production),
 //            epilogue_rows_halves (same in 64-KiB of LDS; persistent kernel), gemm_epilogue (direct; small tiles).
+#include <type_traits>
 #include "common.h"
 #include "vitamd_internal.h"
 
@@ -670,6 +671,197 @@ int launch_pipe(const GemmNtArgs& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ping-pong kernel (round 2): (32 MT) x 256 x 64 tile (MT = 8: 256 rows, MT = 10: 320 rows), 8 waves (2 x 4, wave tile 16 MT x 64),
+// two K-tile buffers, LDS-DMA that never drains.  PMC on the pipe kernel above (profiles/r02/a_baseline_pmc_mfma.json): MFMA
+// pipe 32-50 % busy, waves parked on s_waitcnt / s_barrier 35-42 % of their cycles - its vmcnt(0) + barrier per K-tile empties
+// the load queue every microsecond.  Here:
+//   * a K-tile is cut into NP = MT/2 A-PARTS (the 32 rows [32 j, 32 j + 32) of BOTH wave rows: 64 rows x 128 B = 8 KiB, one
+//     1-KiB DMA piece per wave) and the B block (256 rows, 4 pieces per wave).  PHASE j of a K-tile multiplies A-part j with the
+//     whole B block (2 x 4 tiles x 2 k-substeps = 16 MFMAs); B's fragments are read once, in phase 0, and stay in registers.  So
+//     every LDS region is read in ONE known phase and is free long before the K-tile ends.
+//   * every phase requests one A piece LA phases ahead of its use and (most phases) one B piece LB phases ahead, into the region
+//     the same part of two K-tiles earlier left.  Waits are COUNTED (never 0 in the loop): the count per phase is computed at
+//     compile time from the request schedule (PpSchedule below).
+//   * phase = [ds_reads | DMA requests | counted wait] s_barrier [16 MFMAs, s_setprio 1] s_barrier; the second wave row (waves 4-7,
+//     the second wave of every SIMD) runs ONE barrier behind the first, so on every SIMD one wave feeds the matrix pipe while its
+//     partner reads LDS and issues DMA (cdna_hip_programming.md section 5, the 8-phase template).
+// Ordering: a region first read in phase n is retired by every wave (its own pieces) in phase n-1, before a barrier that both
+// groups pass ahead of any phase-n read (RAW); a region is refilled >= 2 phases after its only read (WAR)  =>  LA, LB <= 2 NP - 2.
+// Requests for K-tiles that do not exist (before the first, past the last) are issued out of range (zero fill, no traffic) so the
+// counts are the same in every phase.  The DMA is issued from inline asm (common.h::asm_glds16): hipcc would otherwise put
+// vmcnt(0) in front of every ds_read.
+template <int NP, int LA, int LB>
+struct PpSchedule {
+  // phase p of K-tile t issues: A-part (p + LA) % NP of K-tile t + (p + LA) / NP ; and B piece q = (p + LB) % NP (if q < 4) of K-tile
+  // t + (p + LB - q) / NP.  Program order inside a phase: A request, then B request.
+  static constexpr int a_part(int p) { return (p + LA) % NP; }
+  static constexpr int a_tile(int p) { return (p + LA) / NP; }
+  static constexpr int b_piece(int p) { return (p + LB) % NP < 4 ? (p + LB) % NP : -1; }
+  static constexpr int b_tile(int p) { return (p + LB - (p + LB) % NP) / NP; }
+  // outstanding requests allowed after phase p's requests so that everything first read in phase p+1 has landed
+  static constexpr int wait(int p) {
+    int allowed = 0;
+    for (int d = 0; d < 4 * NP; ++d) {          // walk back over the phases p, p-1, ... (program order reversed: B then A)
+      const int ph = ((p - d) % NP + NP) % NP;
+      if (b_piece(ph) >= 0) {
+        if (d + 1 >= LB - b_piece(ph)) return allowed;      // needed in phase (p-d) + LB - q <= p+1
+        ++allowed;
+      }
+      if (d + 1 >= LA) return allowed;                         // A request of phase p-d is needed in phase p-d+LA <= p+1
+      ++allowed;
+    }
+    return allowed;
+  }
+  static constexpr int lookback = (LA > LB ? LA : LB);          // phases before the first whose requests the prologue replays
+};
+
+template <int EPI, int MT, int LA, int LB>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmNtArgs p) {
+  constexpr int NP = MT / 2;
+  static_assert(MT % 2 == 0 && LA >= 2 && LA <= 2 * NP - 2 && LB >= 5 && LB <= 2 * NP - 2, "request leads");
+  using S = PpSchedule<NP, LA, LB>;
+  constexpr int BM = 32 * MT, BN = 256, WN = 4, NT = 4;
+  constexpr int PART = 64 * 128;                  // bytes of an A-part
+  constexpr int BUFB = NP * PART + 256 * 128;     // one K-tile buffer: A-parts, then the B block
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tm, tn;
+  tile_coords(tile, tiles_m, tiles_n, tiles_n >= 6, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int K = p.K;
+  const int nkt = K / 64;
+
+  const srd_t srdA = make_srd(p.A, (size_t)p.M * K * 2);
+  const srd_t srdB = make_srd(p.B, (size_t)p.N * K * 2);
+  // this wave's piece of A-part j: LDS rows 8*wave + (lane>>3) of the part = rows 32 j + (lr&31) of wave row lr>>5;
+  // its piece q of the B block: rows 64 q + 8*wave + (lane>>3).  16-B chunk lane&7, XOR (row&7) on the source side.
+  unsigned voffA[NP], voffB[4];
+  {
+    const int lr = 8 * wave + (lane >> 3);
+    const unsigned chunk = (unsigned)(((lane & 7) ^ (lr & 7)) * 16);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int ga = min(m0 + (lr >> 5) * (16 * MT) + j * 32 + (lr & 31), p.M - 1);     // clamp: rows past M are never stored
+      voffA[j] = (unsigned)ga * (unsigned)(K * 2) + chunk;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int gb = min(n0 + 64 * q + lr, p.N - 1);
+      voffB[q] = (unsigned)gb * (unsigned)(K * 2) + chunk;
+    }
+  }
+  const unsigned lds0 = lds_addr(smem) + wave * 1024;
+  constexpr unsigned OOB = 0x80000000u;
+  auto request_a = [&](int kt, int j) {
+    const bool live = kt >= 0 && kt < nkt;
+    asm_glds16(srdA, lds0 + (kt & 1) * BUFB + j * PART, live ? voffA[j] : OOB, live ? (unsigned)kt * 128u : 0u);
+  };
+  auto request_b = [&](int kt, int q) {
+    const bool live = kt >= 0 && kt < nkt;
+    asm_glds16(srdB, lds0 + (kt & 1) * BUFB + NP * PART + q * 8192, live ? voffB[q] : OOB, live ? (unsigned)kt * 128u : 0u);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: 16-row tile at LDS row rb: lane -> row rb + (lane&15), chunk ((lane>>4) + 4 ks) ^ (row&7); k-substep 1 flips
+  // chunk bit 2 = XOR 64 on the swizzled offset, hence one base pointer per substep
+  const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7)) & 7) << 4);
+  const char* const rdA[2] = {smem + wm * 32 * 128 + frag_off, smem + wm * 32 * 128 + (frag_off ^ 64)};                    // + part*PART + i*2048 (+ buffer)
+  const char* const rdB[2] = {smem + NP * PART + wn * 64 * 128 + frag_off, smem + NP * PART + wn * 64 * 128 + (frag_off ^ 64)};   // + j*2048 (+ buffer)
+
+#define VITAMD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  // prologue: replay the requests of the S::lookback phases before phase 0 (those for K-tiles < 0 go out of range: the queue then
+  // looks exactly as in steady state and the same counted waits apply from the first phase on)
+#pragma unroll
+  for (int P = -S::lookback; P < 0; ++P) {
+    const int ph = ((P % NP) + NP) % NP, t = (P - ph) / NP;      // P = NP * t + ph, t < 0
+    request_a(t + S::a_tile(ph), S::a_part(ph));
+    if (S::b_piece(ph) >= 0) request_b(t + S::b_tile(ph), S::b_piece(ph));
+  }
+  VITAMD_WAIT_VM(S::wait(NP - 1));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();        // second wave row: one barrier behind from here on
+
+  bf16x8 bq[NT][2], af[2][2];
+  auto ktile = [&](int kt, auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+    for (int ph = 0; ph < NP; ++ph) {
+      // ---- read section
+      if (ph == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) bq[j][ks] = *(const bf16x8*)(rdB[ks] + BUF * BUFB + j * 2048);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(rdA[ks] + BUF * BUFB + ph * PART + i * 2048);
+      request_a(kt + S::a_tile(ph), S::a_part(ph));
+      if (S::b_piece(ph) >= 0) request_b(kt + S::b_tile(ph), S::b_piece(ph));
+      VITAMD_WAIT_VM(S::wait(ph));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- matrix section: A-part ph x the whole B block
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[2 * ph + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j][ks], af[i][ks], acc[2 * ph + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    ktile(kt, std::integral_constant<int, 0>{});
+    ktile(kt + 1, std::integral_constant<int, 1>{});
+  }
+  if (kt < nkt) ktile(kt, std::integral_constant<int, 0>{});
+  if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // past-the-end requests (zeros) land before the epilogue reuses LDS
+#undef VITAMD_WAIT_VM
+  if constexpr (EPI == EPI_F32) gemm_epilogue<BN, 2, WN, 16 * MT, 64, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+  else if (p.N % 8 == 0 && p.ldo % 8 == 0) gemm_epilogue_rows<EPI, MT>(p, acc, m0, n0, wm, wn, lane, tid, wave, smem);
+  else gemm_epilogue<BN, 2, WN, 16 * MT, 64, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+}
+
+template <int EPI, int MT, int LA, int LB>
+int launch_pp(const GemmNtArgs& p, hipStream_t stream) {
+  constexpr int BM = 32 * MT;
+  constexpr int ops_b = 2 * ((MT / 2) * 8192 + 32768), epi_b = 8 * MT * 2048;     // operand buffers / epilogue images
+  constexpr int lds = ops_b > epi_b ? ops_b : epi_b;
+  auto kern = gemm_nt_pp_kernel<EPI, MT, LA, LB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return VITAMD_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Deep-prefetch variant of the 256x256 kernel: BK = 32 stages of 32 KiB in an NS-deep LDS ring
 // (4 -> 128 KiB).  Ablation of the 2-buffer kernel (tools/ablate_gemm.py, profiles/r01) showed the
 // main loop is bound by operand-fetch LATENCY, not MFMA rate: with one K-tile of prefetch distance
@@ -1113,6 +1305,14 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   }
   if constexpr (EPI != EPI_F32) {
     if (tile == 6) return (ring_ok && p.K % 64 == 0 && p.N % 8 == 0 && p.ldo % 8 == 0) ? launch_persist<EPI>(p, stream) : VITAMD_ERR_SHAPE;
+  }
+  if (tile >= 7 && tile <= 9) {
+    if (!(ring_ok && p.K % 64 == 0)) return VITAMD_ERR_SHAPE;
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU) {
+      if (tile == 9) return launch_pp<EPI, 10, 6, 6>(p, stream);
+      if (tile == 8) return launch_pp<EPI, 10, 4, 6>(p, stream);
+    }
+    return launch_pp<EPI, 8, 4, 6>(p, stream);
   }
   if (tile == 3) return ring_ok ? launch_deep<EPI, 3>(p, stream) : VITAMD_ERR_SHAPE;
   if (tile == 4) return ring_ok ? launch_deep<EPI, 4>(p, stream) : VITAMD_ERR_SHAPE;

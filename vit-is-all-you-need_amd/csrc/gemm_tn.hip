@@ -320,6 +320,164 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn16_kernel(const GemmTnArgs a, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong form of the same GEMM (the production kernel since round 2).  PMC on the kernel above: MFMA pipe 28 % busy, waves
+// parked on s_waitcnt / s_barrier 57 % of their cycles (profiles/r02/a_baseline_pmc_mfma.json) - its one vmcnt(0) + barrier
+// per 64-row stage drains the load queue every microsecond.  Here nothing ever drains:
+//   * the reduction rows are the slow dimension of BOTH operands, so a 64-row stage splits into four 16-row QUARTERS of whole
+//     512-B rows (16 KiB: 8 KiB of L, 8 KiB of Rm) and one 32x32x16 k-step consumes exactly one quarter: a quarter's LDS slot is
+//     free again as soon as its k-step is read, long before the rest of the stage;
+//   * LDS is a ring of NQ quarter slots filled by LDS-DMA (2 one-KiB pieces per wave per quarter) D quarters ahead of the reads,
+//     behind a COUNTED s_waitcnt vmcnt(2(D-1)) - never 0 inside the loop;
+//   * one PHASE per quarter: [transposed reads of the quarter's fragments | 2 DMA pieces | counted wait] s_barrier
+//     [8 MFMAs = 256 matrix-pipe cycles] s_barrier, and the waves of the second wave row (wave >= 4: the second wave of every
+//     SIMD) run ONE barrier behind the first: while one wave of a SIMD issues its MFMAs its partner reads LDS and issues DMA.
+// Ordering (cdna_hip_programming.md section 5, "Read a staged buffer one phase AFTER the wait that retires it"): quarter q is
+// read in phase q by both groups; every wave retires ITS pieces of quarter q by the counted wait of phase q-1, which precedes
+// a barrier both groups pass before any phase-q read (RAW); the slot of quarter q is refilled with quarter q+NQ in phase
+// q+NQ-D >= q+2, two barriers after the later group's reads of it have been waited for (WAR)  =>  D <= NQ-2.
+// Past-the-end quarters are still "loaded" (range-checked to zeros, no traffic) so the vmcnt arithmetic is uniform.
+constexpr int QSLOT = 16 * 512 * 2;   // bytes of one quarter slot
+
+template <bool WS, int NQ, int D>
+__global__ __launch_bounds__(NW * 64) void gemm_tn_pp_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
+  static_assert(D >= 2 && D <= NQ - 2, "prefetch distance: WAR rule");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / WQ, wq = wave % WQ;
+
+  const int ntile = tiles_p * tiles_q;
+  const int id = xcd_remap(blockIdx.x, ntile * splits);
+  const int split = id / ntile, tile = id % ntile;
+  const int p0 = (tile / tiles_q) * BP, q0 = (tile % tiles_q) * BQ;
+  const int nsteps = (a.R + BR - 1) / BR;
+  const int s_lo = (int)((long)nsteps * split / splits), s_hi = (int)((long)nsteps * (split + 1) / splits);
+  if (s_lo >= s_hi) return;
+  const int g_lo = 4 * s_lo, g_hi = 4 * s_hi;      // quarters (16 reduction rows each)
+
+  const bool isL = wave < NW / 2;
+  const int ld = isL ? a.ldl : a.ldr;
+  const int c0 = isL ? p0 : q0;
+  const int ncols = isL ? a.P : a.Q;
+  const srd_t srd = isL ? make_srd(a.L, (size_t)a.R * a.ldl * 2) : make_srd(a.Rm, (size_t)a.R * a.ldr * 2);
+  // this wave's two pieces of a quarter: rows 4*(wave&3) + 2*i + (lane>>5) of its operand, chunk = lane&31 (swizzled)
+  unsigned voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = ((wave & 3) * 2 + i) * 2 + (lane >> 5);
+    const int logical = (lane & 31) ^ ((row & 3) << 2);
+    const int col = c0 + logical * 8;
+    voff[i] = (col < ncols) ? (unsigned)(((size_t)row * ld + col) * 2) : 0x80000000u;
+  }
+  const unsigned qbytes = (unsigned)16 * ld * 2;             // global bytes per quarter
+  const unsigned dst0 = lds_addr(smem) + (isL ? 0 : 8192) + (wave & 3) * 2048;  // this wave's pieces inside slot 0
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int h = lane >> 5, colhalf = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int rowpart = (8 * h + qq) * 512 + (pp & 1) * 8;
+  int offA[MT], offB[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int chunk = (wp * (BP / WP) + i * 32) / 8 + 2 * colhalf + (pp >> 1);
+    offA[i] = rowpart + ((chunk ^ (qq << 2)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int chunk = (wq * (BQ / WQ) + j * 32) / 8 + 2 * colhalf + (pp >> 1);
+    offB[j] = 8192 + rowpart + ((chunk ^ (qq << 2)) << 4);
+  }
+
+  // prologue: quarters g_lo .. g_lo+D-1
+  int slot_w = 0;                                   // slot the next issued quarter goes to
+  unsigned soff = (unsigned)g_lo * qbytes;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const unsigned dst = dst0 + slot_w * QSLOT;
+    asm_glds16(srd, dst, voff[0], soff);
+    asm_glds16(srd, dst + 1024, voff[1], soff);
+    soff += qbytes;
+    slot_w = slot_w + 1 == NQ ? 0 : slot_w + 1;
+  }
+  static_assert(D <= 8, "add a vmcnt literal");
+#define VITAMD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  VITAMD_WAIT_VM(2 * (D - 1));                      // quarter g_lo landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();                     // ... and everyone's
+  asm volatile("" ::: "memory");
+  if (wp == 1) __builtin_amdgcn_s_barrier();        // second wave row runs one barrier behind from here on
+  int slot_r = 0;
+  for (int g = g_lo; g < g_hi; ++g) {
+    // ---- read section
+    const char* q = smem + slot_r * QSLOT;
+    bf16x8 af[MT], bfr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = tr_frag(q + offB[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = tr_frag(q + offA[i]);
+    {
+      const unsigned dst = dst0 + slot_w * QSLOT;
+      asm_glds16(srd, dst, voff[0], soff);
+      asm_glds16(srd, dst + 1024, voff[1], soff);
+      soff += qbytes;
+      slot_w = slot_w + 1 == NQ ? 0 : slot_w + 1;
+    }
+    VITAMD_WAIT_VM(2 * (D - 1));                    // my pieces of quarter g+1 have landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- matrix section
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    slot_r = slot_r + 1 == NQ ? 0 : slot_r + 1;
+  }
+  if (wp == 0) __builtin_amdgcn_s_barrier();        // balance the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the past-the-end pieces (zeros) must not outlive the workgroup's LDS
+#undef VITAMD_WAIT_VM
+
+  if constexpr (WS) {
+    float* wt = a.ws + ((size_t)split * ntile + tile) * (BP * BQ);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ql = wq * (BQ / WQ) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int pl = wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wt[(pl + (r & 3) + 8 * (r >> 2)) * BQ + ql] = acc[i][j][r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int q = q0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int pbase = p0 + wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = pbase + (r & 3) + 8 * (r >> 2);
+          if (p < a.P && q < a.Q) atomicAdd(a.out + (size_t)p * a.ldo + q, acc[i][j][r]);
+        }
+      }
+    }
+  }
+}
+
 // out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; one float4 per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int Q, int ldo,
                                                             int tiles_q, int ntile, int splits, int accumulate) {
@@ -389,7 +547,8 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
       // the NT kernel is 1.1 ms slower with it; tools/ab_dbg.py).  dbg bits 26-28: 5 = LDS-DMA form, 1-3 = timing-only ablations
       const int sel = (g_vitamd_debug >> 26) & 7;
       auto kern = sel == 1 ? gemm_tn_kernel<true, 1> : sel == 2 ? gemm_tn_kernel<true, 2> : sel == 3 ? gemm_tn_kernel<true, 3>
-                : sel == 5 ? gemm_tn_kernel<true, 0> : gemm_tn_kernel<true, 4>;
+                : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_pp_kernel<true, 8, 4> : sel == 7 ? gemm_tn_pp_kernel<true, 8, 6>
+                : gemm_tn_kernel<true, 4>;
       static bool attr_sel[8] = {};
       if (!attr_sel[sel]) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return VITAMD_ERR_LAUNCH;

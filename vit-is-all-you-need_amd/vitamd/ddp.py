@@ -14,12 +14,19 @@ enough that the last bucket's latency after backward ends is < 1 ms.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
 
+CLEAN, LOCAL, REDUCING = 0, 1, 2
+
+
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "work", "launched")
+    """One flat fp32 all-reduce unit.  state: CLEAN = no gradient of this step yet; LOCAL = holds this rank's (possibly
+    accumulated) gradients, not reduced; REDUCING = its all-reduce has been enqueued (nothing may write it before finish())."""
+    __slots__ = ("flat", "params", "offsets", "pending", "work", "launched", "state", "seen")
 
     def __init__(self, params, device):
         self.params = params
@@ -31,11 +38,20 @@ class _Bucket:
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.pending = len(params)
         self.work = None
-        self.launched = False
+        self.launched = False          # written in place by the transformer stack's backward this step
+        self.state = CLEAN
+        self.seen = [False] * len(params)
 
     def view(self, i):
         p = self.params[i]
         return self.flat[self.offsets[i]: self.offsets[i] + p.numel()].view_as(p)
+
+    def reset(self):
+        self.pending = len(self.params)
+        self.work = None
+        self.launched = False
+        self.state = CLEAN
+        self.seen = [False] * len(self.params)
 
 
 class DataParallel(torch.nn.Module):
@@ -43,13 +59,22 @@ class DataParallel(torch.nn.Module):
 
         model = DataParallel(ViTClassifier(cfg).cuda())
         loss = loss_fn(model(x_shard), y_shard); loss.backward(); model.finish(); optim.step()
-    """
+
+    Contract (checked, not assumed):
+      * one backward per finish().  A second backward while buckets are being reduced raises; for gradient accumulation run the
+        first micro-batches under `with model.no_sync():` (gradients add up locally, nothing is exchanged) and the last one outside.
+      * `zero_grad(set_to_none=False)` on the wrapped module is fine: when a parameter's .grad already aliases its bucket slice the
+        stack backward writes into a private arena and autograd adds that into the slice (the in-place fast path needs .grad = None).
+      * a parameter that received no gradient this step counts as zero: finish() zeroes its slice and reduces the bucket then.  The
+        SET of such parameters must be the same on every rank (collectives are issued in bucket order), as in torch's DDP.
+      * every rank must construct its DataParallel wrappers in the same order."""
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 32.0, process_group=None, broadcast: bool = True):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._sync = True
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
@@ -85,9 +110,11 @@ class DataParallel(torch.nn.Module):
             self.buckets.append(_Bucket(cur, cur[0].device))
         for lb in self._stack_layers.values():
             self.buckets.extend(reversed(lb))
+        from . import functions
         if self._stack_layers:
-            from . import functions
-            functions.GradSink.sink = self
+            functions.GradSink.register(self)
+        # the broadcast above wrote parameters through .data (no version bump): drop every cached bf16 weight copy
+        functions.WEIGHTS.clear()
         self._slot = {}
         for b in self.buckets:
             for i, p in enumerate(b.params):
@@ -95,19 +122,53 @@ class DataParallel(torch.nn.Module):
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def forward(self, *a, **kw):
+        for b in self.buckets:         # a new pass: arrival tracking starts over (bucket CONTENTS and state persist)
+            if b.state != REDUCING:
+                b.pending = len(b.params)
+                b.seen = [False] * len(b.params)
+                b.launched = False
         return self.module(*a, **kw)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """gradient accumulation: backward passes inside add into the buckets locally; the first backward outside reduces the sum"""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def _reduce(self, b, stream=None):
+        """enqueue the averaging all-reduce of bucket b (on `stream` if given)"""
+        b.state = REDUCING
+        if self.world == 1:
+            return
+        with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+            b.flat.div_(self.world)  # pre-divide: sum of shares = mean, works on every backend
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    _TWICE = ("vitamd.ddp: backward ran again before finish() - the buckets of the previous backward are still being "
+              "all-reduced.  Call finish() after every backward, or run the earlier micro-batches of a gradient-accumulation "
+              "step under `with model.no_sync():`")
 
     # ---- gradient sink interface (called from functions.TransformerStackFn.backward) ----
     def owns(self, params):
         return tuple(id(p) for p in params) in self._stack_layers
 
     def arena_for(self, params, n_layers):
+        """Per-layer gradient views INTO the buckets (the stack backward then writes them in place), or None when that is not
+        safe this time - the caller then uses a private arena and the hooks copy it / autograd accumulates it into the buckets."""
         lb = self._stack_layers.get(tuple(id(p) for p in params))
         if lb is None or len(lb) != n_layers:
             return None
+        if any(b.state == REDUCING for b in lb):
+            raise RuntimeError(self._TWICE)
+        if not self._sync or any(b.state != CLEAN for b in lb) or any(p.grad is not None for b in lb for p in b.params):
+            return None               # accumulation, or .grad already aliases the bucket (zero_grad(set_to_none=False))
         out = []
         for b in lb:
             b.flat.zero_()            # the kernels accumulate (atomics / column sums) into the bucket
+            b.launched = True
             out.append(tuple(b.view(i) for i in range(6)))
         return out
 
@@ -115,8 +176,10 @@ class DataParallel(torch.nn.Module):
         """every gradient of layer i is enqueued (input-gradient chain on the current stream, weight
         gradients on the side stream): reduce its bucket on the side stream, behind both"""
         b = self._stack_layers[tuple(id(p) for p in params)][i]
-        b.launched = True
+        if not b.launched:            # this backward went through the private arena: the hooks drive the bucket
+            return
         if self.world == 1:
+            b.state = REDUCING
             return
         from .functions import SIDE
         main = torch.cuda.current_stream()
@@ -125,31 +188,44 @@ class DataParallel(torch.nn.Module):
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
-        with torch.cuda.stream(side):
-            b.flat.div_(self.world)
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._reduce(b, side if side is not main else None)
 
     def _on_grad(self, p):
         b, i = self._slot[p]
         v = b.view(i)
         if b.launched:
             p.grad = v           # already written in place (and possibly already being reduced)
-        elif p.grad.data_ptr() != v.data_ptr():
-            v.copy_(p.grad)
-            p.grad = v           # the bucket slice IS the gradient from here on
-        b.pending -= 1
-        if b.pending == 0 and self.world > 1 and not b.launched:
-            b.flat.div_(self.world)  # pre-divide: sum of shares = mean, works on every backend
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.seen[i] = True
+            return
+        if b.state == REDUCING:
+            raise RuntimeError(self._TWICE)
+        if p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)      # .grad was None before this pass (fresh tensor): whatever the slice held is stale
+            p.grad = v           # the bucket slice IS the gradient from here on; later passes accumulate into it in place
+        if not b.seen[i]:
+            b.seen[i] = True
+            b.pending -= 1
+        b.state = LOCAL
+        if b.pending == 0 and self._sync:
+            self._reduce(b)
 
     def finish(self):
-        """Wait for every outstanding bucket (call after backward, before the optimiser step)."""
+        """Wait for every outstanding bucket (call after backward, before the optimiser step).  Buckets that hold gradients
+        but were not launched (some parameter got no gradient this step) are reduced here, in bucket order, with the slices of
+        parameters whose .grad is None counted as zero.  Under no_sync() this only keeps the local sums."""
+        if self._sync:
+            for b in self.buckets:
+                if b.state == LOCAL:
+                    for i, p in enumerate(b.params):
+                        if p.grad is None:
+                            b.view(i).zero_()
+                    self._reduce(b)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-            b.pending = len(b.params)
-            b.launched = False
+            if b.state == REDUCING:
+                b.reset()
 
     def zero_grad(self, set_to_none: bool = True):
         # gradients live in the buckets; dropping the references is enough (hooks re-attach views)

@@ -184,11 +184,27 @@ SIDE = _Side()
 
 
 class GradSink:
-    """Optional hook for data-parallel training (vitamd/ddp.py installs one): lets the transformer
+    """Optional hook for data-parallel training (vitamd/ddp.py registers one per DataParallel wrapper): lets the transformer
     stack's backward write each layer's parameter gradients straight into that layer's all-reduce
     bucket and start the bucket's all-reduce the moment the layer is finished, instead of after the
     whole stack (which is a single autograd node) has returned."""
-    sink = None
+    _sinks = []          # weak references: a wrapper that is garbage-collected drops out by itself
+
+    @classmethod
+    def register(cls, sink):
+        cls._sinks = [r for r in cls._sinks if r() is not None and r() is not sink]
+        cls._sinks.append(weakref.ref(sink))
+
+    @classmethod
+    def find(cls, params):
+        """the registered sink that owns exactly this transformer stack's parameters, or None"""
+        if params is None:
+            return None
+        for r in cls._sinks:
+            s = r()
+            if s is not None and s.owns(params):
+                return s
+        return None
 
 
 def layer_sizes(D):
@@ -200,10 +216,11 @@ def grad_arena(D, n_layers, device, params=None):
     (dWqkv, dbqkv, dW1, db1, dW2, db2) views.  One buffer + one memset by default; the gradient
     sink's per-layer buckets when one is installed for these parameters."""
     sizes, shapes = layer_sizes(D)
-    if GradSink.sink is not None and params is not None:
-        got = GradSink.sink.arena_for(params, n_layers)
+    sink = GradSink.find(params)
+    if sink is not None:
+        got = sink.arena_for(params, n_layers)
         if got is not None:
-            return got
+            return got, sink
     per = sum(sizes)
     flat = torch.zeros(per * n_layers, dtype=F32, device=device)
     out = []
@@ -213,7 +230,7 @@ def grad_arena(D, n_layers, device, params=None):
             views.append(flat[off: off + n].view(sh))
             off += n
         out.append(tuple(views))
-    return out
+    return out, None
 
 
 def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, have_db2=False, emit_bf16=False,
@@ -300,7 +317,7 @@ class TransformerLayerFn(torch.autograd.Function):
     def backward(ctx, g):
         B, N, D, H, causal, xdtype = ctx.meta
         wqkv, w1, w2 = ctx.weights
-        (grads,) = grad_arena(D, 1, g.device)
+        (grads,), _ = grad_arena(D, 1, g.device)
         g0, _ = layer_backward(_f32c(g).view(B * N, D), ctx.saved_tensors, wqkv, w1, w2, B, N, H, causal, grads, drop=ctx.drop)
         join_side(g.device)
         return (g0.view(B, N, D).to(xdtype), *grads, None, None, None, None)
@@ -340,8 +357,7 @@ class TransformerStackFn(torch.autograd.Function):
         params = ctx.params
         n_saved = len(saved_all) // L
         cur = _f32c(g).view(B * N, D)
-        arena = grad_arena(D, L, cur.device, params)
-        sink = GradSink.sink if (GradSink.sink is not None and GradSink.sink.owns(params)) else None
+        arena, sink = grad_arena(D, L, cur.device, params)     # sink: the DDP wrapper whose buckets the arena lives in (or None)
         dy2 = None
         for i in reversed(range(L)):
             wqkv, _, w1, _, w2, _ = params[6 * i: 6 * i + 6]
