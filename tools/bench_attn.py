@@ -1,0 +1,34 @@
+"""Attention forward / backward on the headline shape (B=256, N=197, H=12): fused backward against the two-kernel form (dbg bit 9)."""
+import os, sys, statistics, ctypes, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
+from vitamd import ops, lib
+L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+dev = torch.device("cuda")
+B, N, H = 256, 197, 12
+g = torch.Generator(device="cpu").manual_seed(5)
+qkv = torch.randn(B * N, 3 * H * 64, generator=g).to(dev, torch.bfloat16)
+d_o = torch.randn(B * N, H * 64, generator=g).to(dev, torch.bfloat16)
+o, lse = ops.attention_fwd(qkv, B, N, H)
+def t(fn, n=10):
+    fn(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n * 1e3
+cfgs = {"two_kernel": 0, "fused": 0x200}
+for a in sys.argv[1:]:
+    k, v = a.split("="); cfgs[k] = int(v, 0)
+res = {k: [] for k in cfgs}; fw = []
+ref = None
+for r in range(5):
+    fw.append(t(lambda: ops.attention_fwd(qkv, B, N, H)))
+    for k, bits in cfgs.items():
+        L.vitamd_set_debug(bits)
+        if r == 0:
+            dq = ops.attention_bwd(qkv, o, lse, d_o, B, N, H); torch.cuda.synchronize()
+            if ref is None: ref = dq.float()
+            else: print(k, "rel diff vs first", float((dq.float() - ref).norm() / ref.norm()))
+        res[k].append(t(lambda: ops.attention_bwd(qkv, o, lse, d_o, B, N, H)))
+L.vitamd_set_debug(0)
+print(f"fwd {statistics.median(fw):7.1f} us   (HBM floor 52 us)")
+for k in cfgs: print(f"bwd {k:12s} {statistics.median(res[k]):7.1f} us  {['%.0f' % v for v in res[k]]}")

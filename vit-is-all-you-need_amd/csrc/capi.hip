@@ -23,7 +23,7 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
   if (epi == 6) epi = EPI_GELU;
   if (epi == 7) epi = EPI_DGELU;
   GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug, 0u, 1.0f, 0u, 0u, 0, dg};
-  if (!(tile >= 0 && tile <= 9) && tile != 128 && tile != 256 && (tile < 21 || tile > 24)) return VITAMD_ERR_ARG;
+  if (!(tile >= 0 && tile <= 19) && tile != 128 && tile != 256 && (tile < 21 || tile > 24)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }
 

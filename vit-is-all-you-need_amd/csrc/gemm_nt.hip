@@ -235,9 +235,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
 #pragma unroll
   for (int it = 0; it < 2 * MT; ++it) {
     const int rloc = rsub + 8 * it;
-    const int m = mbase + 8 * it;
+    const int m_true = mbase + 8 * it;
+    const int m = (p.dbg & 4) ? m_true % 640 : m_true;          // dbg bit 2: timing-only, every tile stores to the same few (L2-resident) rows
     const u32x4 v = *(const u32x4*)(tile + rloc * 128 + pc * 16);
-    const bool ok = m < p.M && ncol_ok && !(p.dbg & 0x10000);   // dbg bit 16: timing-only, no output stores
+    const bool ok = m_true < p.M && ncol_ok && !(p.dbg & 0x10000);   // dbg bit 16: timing-only, no output stores
     if constexpr (EPI == EPI_BIAS_BF16) {
       if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
     } else if constexpr (EPI == EPI_GELU) {
@@ -690,6 +691,8 @@ int launch_pipe(const GemmNtArgs& p, hipStream_t stream) {
 // Requests for K-tiles that do not exist (before the first, past the last) are issued out of range (zero fill, no traffic) so the
 // counts are the same in every phase.  The DMA is issued from inline asm (common.h::asm_glds16): hipcc would otherwise put
 // vmcnt(0) in front of every ds_read.
+constexpr int PP_STAGGER_GROUPS = 1;   // 1 = no stagger
+
 template <int NP, int LA, int LB>
 struct PpSchedule {
   // phase p of K-tile t issues: A-part (p + LA) % NP of K-tile t + (p + LA) / NP ; and B piece q = (p + LB) % NP (if q < 4) of K-tile
@@ -746,12 +749,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmNtArgs p) {
     const unsigned chunk = (unsigned)(((lane & 7) ^ (lr & 7)) * 16);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const int ga = min(m0 + (lr >> 5) * (16 * MT) + j * 32 + (lr & 31), p.M - 1);     // clamp: rows past M are never stored
+      const int ga = min(((p.dbg & 0x40000) ? (m0 & 0x3ff) : m0) + (lr >> 5) * (16 * MT) + j * 32 + (lr & 31), p.M - 1);     // clamp: rows past M are never stored (dbg bit 18, timing only: every tile loads one of a few L2-resident panels)
       voffA[j] = (unsigned)ga * (unsigned)(K * 2) + chunk;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int gb = min(n0 + 64 * q + lr, p.N - 1);
+      const int gb = min(((p.dbg & 0x40000) ? 0 : n0) + 64 * q + lr, p.N - 1);
       voffB[q] = (unsigned)gb * (unsigned)(K * 2) + chunk;
     }
   }
@@ -779,6 +782,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmNtArgs p) {
   const char* const rdB[2] = {smem + NP * PART + wn * 64 * 128 + frag_off, smem + NP * PART + wn * 64 * 128 + (frag_off ^ 64)};   // + j*2048 (+ buffer)
 
 #define VITAMD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  // First-round stagger: all workgroups of a launch start together and would reach their (HBM-write-bound) epilogues together,
+  // with the matrix pipes idle meanwhile; delaying workgroup group g = (blockIdx / 8) % P of the FIRST round by g/P of a tile
+  // period puts the groups' epilogues at different times for the rest of the launch (successors inherit the offset).
+  // dbg bits 20-23 = P (0 = default), bits 8-15 = delay unit per group in ~us (0 = default, 255 = off).
+  {
+    const int req = (p.dbg >> 8) & 0xff;
+    int P = (p.dbg >> 20) & 0xf;
+    if (P == 0) P = PP_STAGGER_GROUPS;
+    const int unit = req == 255 ? 0 : (req ? req : max(1, (2 * nkt + 6) / P));      // tile period ~ (2 us per K-tile + epilogue) / P
+    if (unit && gridDim.x > 256 && blockIdx.x < 256) {
+      const int g = (blockIdx.x >> 3) % P;
+      for (int i = 0; i < unit * g; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   // prologue: replay the requests of the S::lookback phases before phase 0 (those for K-tiles < 0 go out of range: the queue then
   // looks exactly as in steady state and the same counted waits apply from the first phase on)
 #pragma unroll
@@ -1298,6 +1315,12 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   if (tile == 1) return ring_ok ? launch_ring<256, 128, 2, 2, EPI>(p, stream) : VITAMD_ERR_SHAPE;
   if (tile == 2) {
     if (!(ring_ok && p.K % 64 == 0)) return VITAMD_ERR_SHAPE;
+    if (p.tile == 0 && !(p.dbg & 0x40000000)) {       // auto: the ping-pong kernel (dbg bit 30 = the round-1 pipe kernel, A/B knob)
+      if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU) {
+        if (prefer_tall(p)) return launch_pp<EPI, 10, 4, 6>(p, stream);
+      }
+      return launch_pp<EPI, 8, 4, 6>(p, stream);
+    }
     if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU) {
       if (p.tile == 0 && prefer_tall(p)) return launch_pipe<EPI, 0, 10>(p, stream);
     }
@@ -1313,6 +1336,22 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
       if (tile == 8) return launch_pp<EPI, 10, 4, 6>(p, stream);
     }
     return launch_pp<EPI, 8, 4, 6>(p, stream);
+  }
+  if constexpr (EPI == EPI_BIAS_BF16) {   // schedule sweep of the ping-pong kernel (tools/bench_nt_bias.py)
+    if (tile >= 10 && tile <= 19 && ring_ok && p.K % 64 == 0) {
+      switch (tile) {
+        case 10: return launch_pp<EPI, 8, 3, 5>(p, stream);
+        case 11: return launch_pp<EPI, 8, 4, 5>(p, stream);
+        case 12: return launch_pp<EPI, 8, 5, 6>(p, stream);
+        case 13: return launch_pp<EPI, 8, 6, 6>(p, stream);
+        case 14: return launch_pp<EPI, 8, 2, 5>(p, stream);
+        case 15: return launch_pp<EPI, 10, 3, 5>(p, stream);
+        case 16: return launch_pp<EPI, 10, 4, 5>(p, stream);
+        case 17: return launch_pp<EPI, 10, 2, 5>(p, stream);
+        case 18: return launch_pp<EPI, 10, 5, 6>(p, stream);
+        default: return launch_pp<EPI, 10, 3, 6>(p, stream);
+      }
+    }
   }
   if (tile == 3) return ring_ok ? launch_deep<EPI, 3>(p, stream) : VITAMD_ERR_SHAPE;
   if (tile == 4) return ring_ok ? launch_deep<EPI, 4>(p, stream) : VITAMD_ERR_SHAPE;

@@ -547,8 +547,8 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
       // the NT kernel is 1.1 ms slower with it; tools/ab_dbg.py).  dbg bits 26-28: 5 = LDS-DMA form, 1-3 = timing-only ablations
       const int sel = (g_vitamd_debug >> 26) & 7;
       auto kern = sel == 1 ? gemm_tn_kernel<true, 1> : sel == 2 ? gemm_tn_kernel<true, 2> : sel == 3 ? gemm_tn_kernel<true, 3>
-                : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_pp_kernel<true, 8, 4> : sel == 7 ? gemm_tn_pp_kernel<true, 8, 6>
-                : gemm_tn_kernel<true, 4>;
+                : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_kernel<true, 4> : sel == 7 ? gemm_tn_pp_kernel<true, 8, 6>
+                : gemm_tn_pp_kernel<true, 8, 4>;      // default: the ping-pong kernel; 6 = the round-1 VGPR-staged kernel
       static bool attr_sel[8] = {};
       if (!attr_sel[sel]) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return VITAMD_ERR_LAUNCH;
@@ -560,7 +560,14 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
                        ntile, splits, a.accumulate);
   } else {
     if (k16) hipLaunchKernelGGL(gemm_tn16_kernel<false>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
-    else hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
+    else {
+      static bool attr_pp = false;
+      if (!attr_pp) {
+        if (hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<false, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return VITAMD_ERR_LAUNCH;
+        attr_pp = true;
+      }
+      hipLaunchKernelGGL((gemm_tn_pp_kernel<false, 8, 4>), dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
+    }
   }
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

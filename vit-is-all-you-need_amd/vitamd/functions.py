@@ -104,7 +104,7 @@ WEIGHTS = WeightCache()
 
 
 ATTN_FUSED_RESID = False  # A/B knob: x1 = x0 + attention written by the attention forward kernel (N <= 256): correct, measured EQUAL (34.47 vs 34.43 ms)
-TN_TARGET_WGS = 180       # workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU)
+TN_TARGET_WGS = 128       # workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU).  Whole-step A/B with the ping-pong kernels (tools/ab_side.py): 128 -> 32.36 ms, 144 -> 32.40, 180 -> 32.86, 96 -> 32.67, 72 -> 35.7
 
 
 def _tn_splits(dW):
@@ -118,6 +118,8 @@ def _tn_splits(dW):
     return max(1, round(TN_TARGET_WGS / ntile))
 
 
+SIDE_POLICY = 0           # A/B knob (tools/ab_side.py): when the MLP weight-gradient GEMMs enter the side stream: 0 = as soon as their inputs exist (beside the
+                          # input-gradient GEMMs), 1 = both after dgrad-fc1 (beside LayerNorm / attention backward), 2 = dW2 beside dgrad-fc1, dW1 after it
 LN_BWD_XHAT = True        # A/B knob (tools/ab_gelu.py): LayerNorm backward reads xhat from the saved bf16 LN output instead of recomputing it from fp32 x
 GELU_STORED_GRAD = True   # A/B knob (tools/ab_gelu.py); False = keep the pre-activation and evaluate gelu' in the backward
 
@@ -273,10 +275,18 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
         ops.gemm_tn(dy2, h, dW2, accumulate=False, splits=_tn_splits(dW2))
         if not have_db2:
             ops.colsum(dy2, db2)
-    on_side(wgrad_fc2, dy2, h, dW2, db2)
+    if SIDE_POLICY == 0:
+        on_side(wgrad_fc2, dy2, h, dW2, db2)
     dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DMUL if GELU_STORED_GRAD else ops.EPI_DGELU, aux=pre, colsum=db1)   # dgrad fc2 . gelu'
-    on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1)), dpre, bln, dW1)
+    if SIDE_POLICY == 0:
+        on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1)), dpre, bln, dW1)
+    if SIDE_POLICY == 2:
+        on_side(wgrad_fc2, dy2, h, dW2, db2)
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
+    if SIDE_POLICY == 1:
+        on_side(wgrad_fc2, dy2, h, dW2, db2)
+    if SIDE_POLICY in (1, 2):
+        on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1)), dpre, bln, dW1)
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True, xhat=bln if LN_BWD_XHAT else None)
     # ---- attention
     dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=dbqkv, dropout=drop[:2])   # also adds the QKV bias gradient
