@@ -28,12 +28,27 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.
 PER_GPU_BATCH = 256
 
 
+def _timed(fns, reps):
+    for f in fns:
+        f()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()                      # our kernels launch on torch's current stream: events see them
+    for _ in range(reps):
+        for f in fns:
+            f()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
 def kernel_roofline(dev):
-    """Live HIP-event timing of the dominant kernel (the NT MFMA GEMM: every forward Linear and
-    every input-gradient GEMM, ~2/3 of the step's FLOPs) at each of the six shapes one step launches
-    it with.  achieved = algorithmic FLOPs (2*M*N*K per launch) / average launch duration, weighted
-    over the launches of one layer, timed in the order the layer issues them."""
-    from vitamd import ops
+    """Live HIP-event timing of the two dominant kernels at the shapes one training step launches them with:
+      gemm_nt_pp_kernel - every forward Linear and every input-gradient GEMM (6 launches per layer, ~2/3 of the step's FLOPs),
+      gemm_tn_pp_kernel - every weight-gradient GEMM (3 launches per layer, split-K reduce pass included).
+    achieved = algorithmic FLOPs (2*M*N*K per launch) / average launch duration over the launches of one layer, timed in the order
+    the layer issues them.  `roofline` itself describes the NT family (the larger share); `kernels` carries both."""
+    from vitamd import ops, functions as F
     M, D = PER_GPU_BATCH * 197, 768
     g = torch.Generator(device="cpu").manual_seed(1)
 
@@ -46,7 +61,7 @@ def kernel_roofline(dev):
     b3, b4, b1 = torch.randn(3 * D, device=dev), torch.randn(4 * D, device=dev), torch.randn(D, device=dev)
     res = torch.randn(M, D, device=dev)
     cs = torch.zeros(4 * D, device=dev)
-    calls = [
+    nt_calls = [
         ("qkv", lambda: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3), 2.0 * M * D * 3 * D),
         ("fc1+gelu", lambda: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4), 2.0 * M * D * 4 * D),
         ("fc2+resid", lambda: ops.gemm_nt(x4, w2, ops.EPI_RESID_F32, bias=b1, aux=res), 2.0 * M * D * 4 * D),
@@ -54,49 +69,72 @@ def kernel_roofline(dev):
         ("dgrad_fc1", lambda: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 4 * D),
         ("dgrad_qkv", lambda: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 3 * D),
     ]
-    def timed(fns, reps):
-        for f in fns:
-            f()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        s.record()                      # our kernels launch on torch's current stream: events see them
-        for _ in range(reps):
-            for f in fns:
-                f()
-        e.record()
-        torch.cuda.synchronize()
-        return s.elapsed_time(e) / reps
+    dWqkv, dW1, dW2 = (torch.empty(s, device=dev) for s in ((3 * D, D), (4 * D, D), (D, 4 * D)))
+    tn_calls = [       # split-K factors as the step chooses them (vitamd.functions._tn_splits)
+        ("dW_fc2", lambda: ops.gemm_tn(x1, x4, dW2, accumulate=False, splits=F._tn_splits(dW2)), 2.0 * M * D * 4 * D),
+        ("dW_fc1", lambda: ops.gemm_tn(x4, x1, dW1, accumulate=False, splits=F._tn_splits(dW1)), 2.0 * M * D * 4 * D),
+        ("dW_qkv", lambda: ops.gemm_tn(x3, x1, dWqkv, accumulate=False, splits=F._tn_splits(dWqkv)), 2.0 * M * D * 3 * D),
+    ]
+    prof = pmc_profile()
 
-    # per shape (informational): ten launches back to back
-    detail = {name: round(flops / timed([fn], 10) / 1e9, 1) for name, fn, flops in calls}
-    # the figure reported: the six launches in the order a layer issues them, eight layers' worth between one pair of events
-    # (a shape repeated back to back with itself sits in a different cache / clock state than inside a step)
-    tot_ms = timed([fn for _, fn, _ in calls], 8)
-    tot_flops = sum(flops for _, _, flops in calls)
-    achieved = tot_flops / tot_ms / 1e9
-    return {"bound": "mfma", "kernel": "gemm_nt_pipe_kernel (256x256x64 / 320x256x64 tiles; the 6 NT GEMM launches of one layer)",
-            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": (pmc_traffic() or {}).get("bytes_per_launch"),
-            "traffic_detail": pmc_traffic(), "per_shape_tflops": detail}
+    def family(calls, kernel):
+        # per shape (informational): ten launches back to back; reported: the launches in layer order, eight layers' worth between one pair of events
+        detail = {name: round(flops / _timed([fn], 10) / 1e9, 1) for name, fn, flops in calls}
+        ms = _timed([fn for _, fn, _ in calls], 8)
+        ach = sum(f for _, _, f in calls) / ms / 1e9
+        return {"kernel": kernel, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "launches_per_layer": len(calls), "avg_launch_us": round(ms * 1e3 / len(calls), 1), "per_shape_tflops": detail,
+                "mfma_util": (prof.get("mfma_util") or {}).get(kernel), "traffic": (prof.get("traffic") or {}).get(kernel)}
 
-
-PMC_PROFILE = os.path.join("profiles", "r01", "m_final_pmc_hbm_traffic.json")
+    nt = family(nt_calls, "gemm_nt_pp_kernel")
+    tn = family(tn_calls, "gemm_tn_pp_kernel")
+    out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel (320x256x64 / 256x256x64 ping-pong tiles; the 6 NT GEMM launches of one layer)",
+           "achieved": nt["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": nt["frac"],
+           "traffic": (nt["traffic"] or {}).get("bytes_per_launch"), "traffic_detail": nt["traffic"], "mfma_util": nt["mfma_util"],
+           "per_shape_tflops": nt["per_shape_tflops"], "kernels": {"gemm_nt_pp_kernel": nt, "gemm_tn_pp_kernel": tn},
+           "pmc_source": prof.get("source")}
+    return out
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of this same bench command folded by tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
-    correction), averaged over the six NT GEMM launches of a layer: QKV (256-row tiles), fc1+GELU, fc2+residual,
-    fc2-dgrad x gelu', fc1-dgrad and QKV-dgrad (320-row tiles).  None if the profile is absent."""
+PMC_DIR = os.path.join("profiles", "r02")
+NT_ALGO_MB = {"<0, 8": 339, "<0, 10": 339, "<1, 10": 702, "<2, 10": 625, "<3, 10": 702}     # algorithmic MB per launch by (EPI, MT) template prefix
+
+
+def pmc_profile():
+    """Per-kernel MFMA utilisation and HBM bytes per launch from the committed rocprofv3 PMC passes of this bench command
+    (profiles/r02/final_pmc_mfma.json: tools/pmc_mfma.py; final_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes folded
+    by tools/pmc_traffic.py with the gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE).  Missing files -> empty."""
+    out = {}
     try:
-        prof = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
-        per = {k.split("gemm_nt_pipe_kernel")[1].split("(")[0]: v["hbm_MB_avg_corrected(2*fetch+write)"]
-               for k, v in prof.items() if "gemm_nt_pipe_kernel<" in k}
-        mb = (per["<0, 0, 8>"] + per["<1, 0, 10>"] + per["<2, 0, 10>"] + per["<3, 0, 10>"] + 2 * per["<0, 0, 10>"]) / 6
-        return {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int((3 * 339 + 702 + 625 + 702) / 6 * 1e6),
-                "source": PMC_PROFILE}
+        mf = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_mfma.json")))
+        util = {}
+        for fam in ("gemm_nt_pp_kernel", "gemm_tn_pp_kernel"):
+            rows = [(v["launches"], v["avg_us_profiled"], v["mfma_util"]) for k, v in mf.items() if fam in k and v["avg_us_profiled"] > 50]
+            if rows:       # time-weighted over the family's launches
+                util[fam] = {"mfma_busy_frac": round(sum(n * t * u for n, t, u in rows) / sum(n * t for n, t, _ in rows), 4),
+                             "per_instantiation": {k.split(fam)[1].split("(")[0]: v["mfma_util"] for k, v in mf.items() if fam in k and v["avg_us_profiled"] > 50}}
+        out["mfma_util"] = util
+        out["source"] = os.path.join(PMC_DIR, "final_pmc_mfma.json")
     except Exception:
-        return None
+        pass
+    try:
+        tr = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_hbm_traffic.json")))
+        traffic = {}
+        nt = {k.split("gemm_nt_pp_kernel")[1].split("(")[0]: v for k, v in tr.items() if "gemm_nt_pp_kernel<" in k and v["launches"] >= 12}
+        if nt:
+            tot_n = sum(v["launches"] for v in nt.values())
+            mb = sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in nt.values()) / tot_n
+            algo = sum(v["launches"] * next((a for pre, a in NT_ALGO_MB.items() if k.startswith(pre)), 0) for k, v in nt.items()) / tot_n
+            traffic["gemm_nt_pp_kernel"] = {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int(algo * 1e6)}
+        tn = [v for k, v in tr.items() if "gemm_tn_pp_kernel<" in k]
+        if tn:
+            tot_n = sum(v["launches"] for v in tn)
+            traffic["gemm_tn_pp_kernel"] = {"bytes_per_launch": int(sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in tn) / tot_n * 1e6),
+                                            "algorithmic_bytes_per_launch": int((387 + 387 + 309) / 3 * 1e6 + 9.4e6)}
+        out["traffic"] = traffic
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline():

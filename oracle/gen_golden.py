@@ -406,10 +406,47 @@ def gen_block_tokenizer_fixture():
     save("blocks_tokenizers.pt", out)
 
 
+def gen_autocast_fixture(RT, TV):
+    """The reference's OWN bf16-autocast results (CPU autocast of the unmodified reference modules), stored as tensors: an
+    independent yardstick for the HIP path that does not pass through oracle/vit_oracle.py's kernel-shaped `lowp` emulation
+    (VERDICT r1 item 3).  Same seeds / shapes as transformer_tiny.pt, transformer_layer_b.pt and vit_s32.pt."""
+    out = {}
+    L, H, D, N, B, seed = 2, 2, 128, 37, 3, 11
+    model = RT.Transformer(RT.TransformerConfig(n_layers=L, n_heads=H, n_embd=D, block_size=N))
+    model.load_state_dict(W.transformer_state(seed, "", L, D), strict=True)
+    x, dy = W.normal(seed, "x", (B, N, D)), W.normal(seed, "dy", (B, N, D))
+    y16, dx16, g16 = run_fwd_bwd(model, x, dy, autocast_bf16=True)
+    out["transformer_tiny"] = {"y": y16, "dx": dx16.float(), "grads": {k: v.float() for k, v in g16.items()}}
+    L, H, D, N, B, seed = 1, 12, 768, 197, 2, 12
+    model = RT.Transformer(RT.TransformerConfig(n_layers=L, n_heads=H, n_embd=D, block_size=N))
+    model.load_state_dict(W.transformer_state(seed, "", L, D), strict=True)
+    x, dy = W.normal(seed, "x", (B, N, D)), W.normal(seed, "dy", (B, N, D))
+    y16, dx16, g16 = run_fwd_bwd(model, x, dy, autocast_bf16=True)
+    out["transformer_layer_b"] = {"y": summarize(y16), "dx": summarize(dx16), "grads": {k: summarize(v) for k, v in g16.items()}}
+    cfg = TV.ViTConfig(32, 3, 16, "S", 1, 0.0)
+    tc = cfg.trans_config
+    model = TV.ViTClassifier(cfg, num_classes=10)
+    seed, batch = 13, 64
+    model.load_state_dict(W.classifier_state(seed, 3, 16, cfg.n_patches, 1, tc.n_layers, tc.n_embd, 10), strict=True)
+    images, labels = W.normal(seed, "images", (batch, 3, 32, 32)), W.randint(seed, "labels", (batch,), 10)
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        logits = model(images)
+        loss = torch.nn.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    out["vit_s32"] = {"logits": logits.detach().float(), "loss": float(loss),
+                      "grads": {k: summarize(p.grad) for k, p in model.named_parameters()}}
+    save("ref_autocast_bf16.pt", out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     RT, TV, RU = import_reference()
+    if "--autocast-only" in sys.argv:          # add the round-2 fixture without touching the others
+        gen_autocast_fixture(RT, TV)
+        return
+    gen_autocast_fixture(RT, TV)
     gen_transformer_fixtures(RT)
     gen_classifier_fixture(TV, "vit_s32.pt", 32, "S", 10, 64, seed=13, full_grads=True)   # BASELINE config 1
     gen_classifier_fixture(TV, "vit_b224.pt", 224, "B", 1000, 2, seed=14)                 # BASELINE config 2 shape

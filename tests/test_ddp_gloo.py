@@ -73,3 +73,102 @@ def test_ddp_world2_matches_single_process():
         for r in range(world):
             for got, p in zip(results[r][step], ref.parameters()):
                 assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# bucket state machine: accumulation, set_to_none=False, parameters without gradient, misuse
+class _Branchy(torch.nn.Module):
+    """two heads; `use_b=False` leaves head_b without gradient for the step"""
+
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Linear(16, 32)
+        self.head_a = torch.nn.Linear(32, 4)
+        self.head_b = torch.nn.Linear(32, 4)
+
+    def forward(self, x, use_b=True):
+        h = torch.nn.functional.gelu(self.body(x))
+        return self.head_a(h) + (self.head_b(h) if use_b else 0.0)
+
+
+def _state_worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "vit-is-all-you-need_amd"))
+    from vitamd.ddp import DataParallel, shard_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = _Branchy()
+    ddp = DataParallel(m, bucket_mb=0.002)
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(16, 16, generator=g), torch.randn(16, 4, generator=g)
+    lo, hi = shard_batch(16, rank, world)
+    mid = (lo + hi) // 2
+    out = {}
+
+    def grads():
+        return [None if p.grad is None else p.grad.detach().numpy().copy() for p in m.parameters()]
+
+    # 1. gradient accumulation: first micro-batch under no_sync, second outside; mean-of-sums convention = sum of the two micro losses
+    ddp.zero_grad()
+    with ddp.no_sync():
+        ((ddp(x[lo:mid]) - y[lo:mid]) ** 2).sum().backward()
+        ddp.finish()                               # a finish() inside no_sync keeps the local sums
+    ((ddp(x[mid:hi]) - y[mid:hi]) ** 2).sum().backward()
+    ddp.finish()
+    out["accum"] = grads()
+    # 2. zero_grad(set_to_none=False) on the wrapped module: .grad stays the (zeroed) bucket view
+    m.zero_grad(set_to_none=False)
+    ((ddp(x[lo:hi]) - y[lo:hi]) ** 2).sum().backward()
+    ddp.finish()
+    out["keep_views"] = grads()
+    # 3. a parameter without gradient this step (same on every rank): its bucket is still reduced, .grad stays None
+    ddp.zero_grad()
+    ((ddp(x[lo:hi], use_b=False) - y[lo:hi]) ** 2).sum().backward()
+    ddp.finish()
+    out["unused"] = grads()
+    # 4. misuse: a second backward while the first one's buckets are being reduced
+    ddp.zero_grad()
+    ((ddp(x[lo:hi]) - y[lo:hi]) ** 2).sum().backward()
+    try:
+        ((ddp(x[lo:hi]) - y[lo:hi]) ** 2).sum().backward()
+        out["twice"] = "no error"
+    except RuntimeError as e:
+        out["twice"] = "raised" if "finish()" in str(e) else f"other: {e}"
+    ddp.finish()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_bucket_state_machine_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_state_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = _Branchy()
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(16, 16, generator=g), torch.randn(16, 4, generator=g)
+
+    def ref_grads(use_b=True):
+        ref.zero_grad(set_to_none=True)
+        (((ref(x, use_b) - y) ** 2).sum() / world).backward()      # ranks average their per-shard SUM losses
+        return [None if p.grad is None else p.grad for p in ref.parameters()]
+
+    full, partial = ref_grads(True), ref_grads(False)
+    for r in range(world):
+        for case, want in (("accum", full), ("keep_views", full), ("unused", partial)):
+            for got, w in zip(results[r][case], want):
+                if w is None:
+                    assert got is None, case
+                else:
+                    assert got is not None and torch.allclose(torch.from_numpy(got), w, rtol=1e-5, atol=1e-6), (r, case)
+        assert results[r]["twice"] == "raised", results[r]["twice"]

@@ -65,35 +65,35 @@ def test_gemm_nt_epilogues(hip, tile):
     # bias -> bf16
     y = ops.gemm_nt(ad, bd, ops.EPI_BIAS_BF16, bias=biasd).float().cpu()
     ref = r16(acc + r16(bias))
-    assert O.rel_l2(y, ref) < 2e-3
+    assert O.rel_l2(y, ref) < 3.2e-5
     # gelu (two outputs)
     pre, act = ops.gemm_nt(ad, bd, ops.EPI_GELU, bias=biasd)
-    assert O.rel_l2(pre.float().cpu(), ref) < 2e-3
+    assert O.rel_l2(pre.float().cpu(), ref) < 3.2e-5
     assert O.rel_l2(act.float().cpu(), r16(O.gelu_erf(pre.float().cpu()))) < 2e-3
     # residual fp32
     res = randn((M, N), 6)
     y = ops.gemm_nt(ad, bd, ops.EPI_RESID_F32, bias=biasd, aux=res.to(dev())).cpu()
-    assert O.rel_l2(y, res + ref) < 1e-3
+    assert O.rel_l2(y, res + ref) < 2.8e-5
     # dgelu + column sums
     prez = r16(randn((M, N), 7))
     cs = torch.zeros(N, device=dev())
     y = ops.gemm_nt(ad, bd, ops.EPI_DGELU, aux=prez.to(dev(), BF16), colsum=cs).float().cpu()
     x = prez.clone().requires_grad_(True)
     O.gelu_erf(x).backward(r16(acc))
-    assert O.rel_l2(y, r16(x.grad)) < 3e-3
-    assert O.rel_l2(cs.cpu(), y.sum(0)) < 1e-4
+    assert O.rel_l2(y, r16(x.grad)) < 5.8e-5
+    assert O.rel_l2(cs.cpu(), y.sum(0)) < 1.0e-6
     # stored-derivative pair: GELU_DG writes gelu'(pre) (bf16) beside gelu(pre); DMUL multiplies by it as stored
     dgl, act2 = ops.gemm_nt(ad, bd, ops.EPI_GELU_DG, bias=biasd)
     assert torch.equal(act2, act)
     xp = ref.clone().requires_grad_(True)
     O.gelu_erf(xp).backward(torch.ones_like(ref))
-    assert O.rel_l2(dgl.float().cpu(), r16(xp.grad)) < 2e-3
+    assert O.rel_l2(dgl.float().cpu(), r16(xp.grad)) < 4.5e-5
     assert float((dgl.float().cpu() - xp.grad).abs().max()) < 6e-3          # bf16 rounding of values up to 1.13
     cs2 = torch.zeros(N, device=dev())
     dg_in = r16(randn((M, N), 17, 0.5))
     y2 = ops.gemm_nt(ad, bd, ops.EPI_DMUL, aux=dg_in.to(dev(), BF16), colsum=cs2).float().cpu()
-    assert O.rel_l2(y2, r16(r16(acc) * dg_in)) < 2e-3
-    assert O.rel_l2(cs2.cpu(), y2.sum(0)) < 1e-4
+    assert O.rel_l2(y2, r16(r16(acc) * dg_in)) < 2.2e-5
+    assert O.rel_l2(cs2.cpu(), y2.sum(0)) < 1.0e-6
     # patch epilogue: row remap + pos add
     n_p, extra = 9, 2
     Bn = 37
@@ -104,7 +104,7 @@ def test_gemm_nt_epilogues(hip, tile):
     got = out.cpu().view(Bn, n_p + extra, N)
     want = r16(a2 @ b.t() + r16(bias)).view(Bn, n_p, N) + pos
     assert torch.all(got[:, :extra] == 7.0)
-    assert O.rel_l2(got[:, extra:], want) < 1e-3
+    assert O.rel_l2(got[:, extra:], want) < 7.7e-6
 
 
 @pytest.mark.parametrize("M", [256 * 197, 50000, 320 * 100 + 7])
@@ -142,7 +142,7 @@ def test_gemm_nt_tall_tile_gelu_epilogues_match_256(hip):
         y1 = ops.gemm_nt(a, b, epi, aux=aux, colsum=c1)
         y2 = ops.gemm_nt(a, b, epi, aux=aux, colsum=c2, tile=2)
         assert torch.equal(y1, y2)
-        assert O.rel_l2(c1.cpu(), c2.cpu()) < 1e-5          # column sums: atomics, order differs
+        assert O.rel_l2(c1.cpu(), c2.cpu()) < 1.0e-6          # column sums: atomics, order differs
 
 
 def test_gemm_nt_rejects_bad_shapes(hip):
@@ -173,6 +173,20 @@ def test_gemm_tn_exact_integers(hip, R, P, Q, splits):
     out = torch.full((P, Q), 123.0, device=dev())
     ops.gemm_tn(ld, rd, out, splits=splits, accumulate=False)   # overwrite mode needs no zeroing
     assert torch.equal(out.cpu(), l.t() @ r)
+
+
+def test_gemm_tn_overwrite_mode_without_workspace_is_refused(hip):
+    """with accumulate = 0 and no (or a too small) split-K workspace the call used to fall through to the atomic kernel,
+    which ADDS into an un-zeroed `out`; it must fail loudly instead."""
+    from vitamd import ops
+    l, r = ints((128, 256), -2, 2, 71).to(dev(), BF16), ints((128, 256), -2, 2, 72).to(dev(), BF16)
+    out = torch.full((256, 256), 5.0, device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    assert hip.vitamd_gemm_tn_bf16_ws(l.data_ptr(), r.data_ptr(), out.data_ptr(), 128, 256, 256, 256, 256, 256, 0, None, 0, 0, st) == 2
+    small = torch.empty(16, device=dev())
+    assert hip.vitamd_gemm_tn_bf16_ws(l.data_ptr(), r.data_ptr(), out.data_ptr(), 128, 256, 256, 256, 256, 256, 0, small.data_ptr(), 64, 0, st) == 2
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), torch.full((256, 256), 5.0))          # untouched
 
 
 @pytest.mark.parametrize("dbg_bits", [64, 5 << 26, 6 << 26, 7 << 26])
@@ -233,21 +247,21 @@ def test_layernorm_fwd_bwd(hip, M, D):
     xr = (x + add).requires_grad_(True)
     yr = O.layer_norm(xr)
     assert O.rel_l2(xs.cpu(), xr) < 1e-6
-    assert O.rel_l2(y.float().cpu(), r16(yr)) < 3e-3
-    assert O.rel_l2(mean.cpu(), xr.mean(-1)) < 1e-5
+    assert O.rel_l2(y.float().cpu(), r16(yr)) < 2.9e-5
+    assert O.rel_l2(mean.cpu(), xr.mean(-1)) < 1.0e-6
     _, y2, _, _ = ops.layernorm_fwd(x.to(dev()))
-    assert O.rel_l2(y2.float().cpu(), r16(O.layer_norm(x))) < 3e-3
+    assert O.rel_l2(y2.float().cpu(), r16(O.layer_norm(x))) < 3.0e-5
     dy = r16(randn((M, D), 23))
     gres = randn((M, D), 24)
     cs = torch.zeros(D, device=dev())
     g, gb = ops.layernorm_bwd(dy.to(dev(), BF16), xs, mean, rstd, g_res=gres.to(dev()), want_bf16=True, colsum=cs)
     yr.backward(dy)
     want = gres + xr.grad
-    assert O.rel_l2(g.cpu(), want) < 1e-5
+    assert O.rel_l2(g.cpu(), want) < 1.0e-6
     assert torch.equal(gb.float().cpu(), r16(g.cpu()))
-    assert O.rel_l2(cs.cpu(), gb.float().cpu().sum(0)) < 1e-4
+    assert O.rel_l2(cs.cpu(), gb.float().cpu().sum(0)) < 1.0e-6
     g2, none = ops.layernorm_bwd(dy.to(dev(), BF16), xs, mean, rstd)
-    assert none is None and O.rel_l2(g2.cpu(), xr.grad) < 1e-5
+    assert none is None and O.rel_l2(g2.cpu(), xr.grad) < 1.0e-6
 
 
 @pytest.mark.parametrize("M,D", [(777, 768), (320, 512), (50, 1024), (5, 256)])
@@ -263,12 +277,12 @@ def test_layernorm_bwd_xhat_mode(hip, M, D):
     c1, c2 = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
     g_ref, gb_ref = ops.layernorm_bwd(dy, x, mean, rstd, g_res=gres, want_bf16=True, colsum=c1)
     g, gb = ops.layernorm_bwd(dy, x, mean, rstd, g_res=gres, want_bf16=True, colsum=c2, xhat=y)
-    assert O.rel_l2(g.cpu(), g_ref.cpu()) < 1e-3
-    assert O.rel_l2(gb.float().cpu(), gb_ref.float().cpu()) < 5e-3          # bf16 roundings may flip the last bit
-    assert O.rel_l2(c2.cpu(), gb.float().sum(0).cpu()) < 1e-4
+    assert O.rel_l2(g.cpu(), g_ref.cpu()) < 7.2e-5
+    assert O.rel_l2(gb.float().cpu(), gb_ref.float().cpu()) < 5.3e-4          # bf16 roundings may flip the last bit
+    assert O.rel_l2(c2.cpu(), gb.float().sum(0).cpu()) < 1.0e-6
     xr = x.cpu().clone().requires_grad_(True)
     O.layer_norm(xr).backward(dy.float().cpu())
-    assert O.rel_l2(g.cpu(), xr.grad + gres.cpu()) < 1e-3
+    assert O.rel_l2(g.cpu(), xr.grad + gres.cpu()) < 7.2e-5
 
 
 # ------------------------------------------------------------------------------------------ attention
@@ -291,19 +305,19 @@ def test_attention_fwd_bwd(hip, B, N, H, causal):
     o_ref, dqkv_ref = _attn_ref(qkv, B, N, H, causal, d_o)
     qd = qkv.to(dev(), BF16)
     o, lse = ops.attention_fwd(qd, B, N, H, causal)
-    assert O.rel_l2(o.float().cpu(), o_ref) < 6e-3
+    assert O.rel_l2(o.float().cpu(), o_ref) < 2.2e-3
     # log-sum-exp (log2 domain) against the definition
     q, k, _ = O.split_qkv(qkv.view(B, N, -1), H)
     s = (q @ k.transpose(-1, -2)) * 0.125
     if causal:
         s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
-    assert O.rel_l2(lse.cpu(), torch.logsumexp(s, -1) / math.log(2.0)) < 1e-4
+    assert O.rel_l2(lse.cpu(), torch.logsumexp(s, -1) / math.log(2.0)) < 1.0e-6
     dbias = torch.full((3 * H * 64,), 1.0, device=dev())
     dqkv = ops.attention_bwd(qd, o, lse, d_o.to(dev(), BF16), B, N, H, causal, dbias=dbias).float().cpu()
-    assert O.rel_l2(dbias.cpu() - 1.0, dqkv.sum(0)) < 2e-4     # fused QKV-bias gradient = column sums of what was stored
+    assert O.rel_l2(dbias.cpu() - 1.0, dqkv.sum(0)) < 1.0e-6     # fused QKV-bias gradient = column sums of what was stored
     D = H * 64
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
-        assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 1.2e-2, name
+        assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 6.4e-3, name
 
 
 @pytest.mark.parametrize("B,N,H,causal", [(1, 513, 1, False), (2, 577, 2, False), (1, 1024, 2, True), (1, 640, 1, True), (1, 1500, 1, False)])
@@ -316,18 +330,18 @@ def test_attention_long_sequences(hip, B, N, H, causal):
     o_ref, dqkv_ref = _attn_ref(qkv, B, N, H, causal, d_o)
     qd = qkv.to(dev(), BF16)
     o, lse = ops.attention_fwd(qd, B, N, H, causal)
-    assert O.rel_l2(o.float().cpu(), o_ref) < 6e-3
+    assert O.rel_l2(o.float().cpu(), o_ref) < 2.3e-3
     q, k, _ = O.split_qkv(qkv.view(B, N, -1), H)
     s = (q @ k.transpose(-1, -2)) * 0.125
     if causal:
         s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
-    assert O.rel_l2(lse.cpu(), torch.logsumexp(s, -1) / math.log(2.0)) < 1e-4
+    assert O.rel_l2(lse.cpu(), torch.logsumexp(s, -1) / math.log(2.0)) < 1.0e-6
     dbias = torch.zeros((3 * H * 64,), device=dev())
     dqkv = ops.attention_bwd(qd, o, lse, d_o.to(dev(), BF16), B, N, H, causal, dbias=dbias).float().cpu()
-    assert O.rel_l2(dbias.cpu(), dqkv.sum(0)) < 2e-4
+    assert O.rel_l2(dbias.cpu(), dqkv.sum(0)) < 1.0e-6
     D = H * 64
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
-        assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 1.2e-2, name
+        assert O.rel_l2(dqkv[:, sl], dqkv_ref[:, sl]) < 5.3e-3, name
 
 
 @pytest.mark.parametrize("B,N,H,causal", [(2, 197, 3, False), (1, 256, 2, True), (3, 37, 2, False), (2, 5, 1, False)])
@@ -353,7 +367,7 @@ def test_attention_softmax_spike(hip):
     qkv[150, 64:128] = r16(qkv[10, 0:64] * 40.0)  # key 150 aligned with query 10
     o_ref, _ = _attn_ref(qkv, B, N, H, False)
     o, _ = ops.attention_fwd(qkv.to(dev(), BF16), B, N, H, False)
-    assert O.rel_l2(o.float().cpu(), o_ref) < 6e-3
+    assert O.rel_l2(o.float().cpu(), o_ref) < 1.0e-6
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -376,4 +390,4 @@ def test_cast_transpose_im2col_colsum_embed(hip):
     assert O.rel_l2(dpos.cpu(), g3[:, extra:].sum(0)) < 1e-6
     assert O.rel_l2(dextra.cpu(), g3[:, :extra].sum(0)) < 1e-6
     assert torch.equal(dyp.float().cpu(), r16(g3[:, extra:]).reshape(-1, D))
-    assert O.rel_l2(dbias.cpu(), r16(g3[:, extra:]).sum((0, 1))) < 1e-5
+    assert O.rel_l2(dbias.cpu(), r16(g3[:, extra:]).sum((0, 1))) < 1.0e-6

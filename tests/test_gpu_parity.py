@@ -67,10 +67,10 @@ def test_transformer_tiny_vs_reference_golden(hip, name):
     yo = O.transformer(x, leaves, "", c["n_layers"], c["n_heads"], c["causal"], lowp=True)
     names = [k for k in leaves if "mask" not in k]
     go = torch.autograd.grad((yo * dyv).sum(), [x] + [leaves[k] for k in names])
-    assert O.rel_l2(y, yo) < 4e-3
-    assert O.rel_l2(dx, go[0]) < 1e-2
+    assert O.rel_l2(y, yo) < 3.8e-4
+    assert O.rel_l2(dx, go[0]) < 2.0e-3
     for k, gk in zip(names, go[1:]):
-        assert O.rel_l2(grads[k], gk) < 1e-2, k
+        assert O.rel_l2(grads[k], gk) < 5.7e-3, k
 
 
 def test_transformer_layer_b_vs_reference_golden(hip):
@@ -135,13 +135,13 @@ def test_standalone_attention_and_layer_modules(hip):
     xo = x.clone().requires_grad_(True)
     yo = O.transformer_layer(xo, sd, "layers.0.", 2, False, lowp=True)
     yo.sum().backward()
-    assert O.rel_l2(y.detach().cpu(), yo.detach()) < 4e-3
-    assert O.rel_l2(xg.grad.cpu(), xo.grad) < 1e-2
+    assert O.rel_l2(y.detach().cpu(), yo.detach()) < 1.8e-5
+    assert O.rel_l2(xg.grad.cpu(), xo.grad) < 1.7e-3
     attn = layer.multi_attn
     xa = O.layer_norm(x)
     ya = attn(xa.cuda())
     yao = O.attention(xa, sd, "layers.0.multi_attn.", 2, False, lowp=True)
-    assert ya.shape == (2, 50, 128) and O.rel_l2(ya.detach().cpu(), yao) < 6e-3
+    assert ya.shape == (2, 50, 128) and O.rel_l2(ya.detach().cpu(), yao) < 1.0e-6
 
 
 def test_full_size_properties(hip):
@@ -165,7 +165,7 @@ def test_full_size_properties(hip):
     (2.0 * torch.nn.functional.cross_entropy(m(images), labels)).backward()
     for k, p in m.named_parameters():
         assert torch.isfinite(p.grad).all(), k
-        assert O.rel_l2(p.grad.cpu(), 2.0 * g1[k].cpu()) < 2e-2, k
+        assert O.rel_l2(p.grad.cpu(), 2.0 * g1[k].cpu()) < 1.4e-6, k
 
 
 def test_adamw_kernel_matches_torch(hip):
@@ -209,7 +209,7 @@ def test_training_steps_match_reference_loop(hip):
     assert abs(losses[0] - ref[0]) < 5e-3
     for a, b in zip(losses, ref):
         assert abs(a - b) < 3e-2 * max(1.0, abs(b)), (losses, ref)
-    assert O.rel_l2(m.head.bias.detach().cpu(), g["final_head_bias"]) < 5e-2
+    assert O.rel_l2(m.head.bias.detach().cpu(), g["final_head_bias"]) < 7.3e-4
 
 
 # ------------------------------------------------------------------ tokenizers (BASELINE configs[3], [4])
@@ -243,7 +243,7 @@ def test_tokenizer_vs_reference_golden(hip, name):
     with torch.no_grad():
         latents = enc(images)
         recon_fixed = m.decode_indices(g["indices"].cuda())     # decoder alone, on the reference's own code sequence
-    assert O.rel_l2(latents.cpu(), g["latents"]) < 2e-2          # latents are 12-dim projections of a 6/12-layer bf16 stack
+    assert O.rel_l2(latents.cpu(), g["latents"]) < 5.7e-3          # latents are 12-dim projections of a 6/12-layer bf16 stack
     assert _err(recon_fixed, g["recon_from_indices"]) < 2 * floor["recon"] + 3e-3
     recon, idx, qloss = m(images)
     agree = float((idx.cpu() == g["indices"]).float().mean())
@@ -285,10 +285,10 @@ def test_single_layer_presets_vs_oracle(hip, preset, seq, batch):
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     yo = O.transformer(xo, leaves, "", 1, H, False, lowp=True)
     go = torch.autograd.grad((yo * dy).sum(), [xo] + list(leaves.values()))
-    assert O.rel_l2(y.detach().cpu(), yo.detach()) < 4e-3
-    assert O.rel_l2(xg.grad.cpu(), go[0]) < 1e-2
+    assert O.rel_l2(y.detach().cpu(), yo.detach()) < 7.0e-4
+    assert O.rel_l2(xg.grad.cpu(), go[0]) < 6.4e-4
     for (k, p), gk in zip(m.named_parameters(), go[1:]):
-        assert O.rel_l2(p.grad.cpu(), gk) < 1.5e-2, k
+        assert O.rel_l2(p.grad.cpu(), gk) < 5.6e-3, k
 
 
 # ------------------------------------------------------------------ blocks.py surface
@@ -326,13 +326,13 @@ def test_blocks_surface_vs_reference_golden(hip, name):
     assert O.rel_l2(y.detach().cpu(), case["y"]) < 2 * floor["y"] + 2e-3
     assert O.rel_l2(x.grad.cpu(), case["dx"]) < 2 * floor["dx"] + 4e-3
     if "dskip" in case:
-        assert O.rel_l2(args[1].grad.cpu(), case["dskip"]) < 2e-2
+        assert O.rel_l2(args[1].grad.cpu(), case["dskip"]) < 5.5e-3
     for k, p in m.named_parameters():
         assert O.rel_l2(p.grad.cpu(), case["grads"][k]) < 2 * floor["grads"][k] + 6e-3, k
     # tight: against the oracle's bf16-flow emulation of the same block
     lo = blocks_oracle_run(name, case, lowp=True)
-    assert O.rel_l2(y.detach().cpu(), lo["y"]) < 5e-3
-    assert O.rel_l2(x.grad.cpu(), lo["dx"]) < 1.2e-2
+    assert O.rel_l2(y.detach().cpu(), lo["y"]) < 5.3e-4
+    assert O.rel_l2(x.grad.cpu(), lo["dx"]) < 5.8e-3
 
 
 # ------------------------------------------------------------------ blocks.py tokenizer wrappers
@@ -364,7 +364,7 @@ def test_block_tokenizers_vs_reference_golden(hip, name, cls):
     # tighter: against the oracle's bf16-flow emulation (8 layers deep: rounding-order differences accumulate)
     assert O.rel_l2(y.detach().cpu(), lo_y) < 1e-2
     for t, ref in zip(ins, lo_dins):
-        assert O.rel_l2(t.grad.cpu(), ref) < 2e-2
+        assert O.rel_l2(t.grad.cpu(), ref) < 1.8e-2
 
 
 @pytest.mark.parametrize("name", ["vq_plain", "vq_l2norm", "vq_wide", "vq_cluster"])
@@ -406,7 +406,7 @@ def test_conv3x3_kernel_vs_oracle(hip):
         torch.cuda.synchronize()
         assert O.rel_l2(y.cpu(), yr.detach()) < 1e-6
         assert O.rel_l2(dx.cpu(), gx) < 1e-6
-        assert O.rel_l2(dw.cpu(), gw) < 2e-5 and O.rel_l2(db.cpu(), gb) < 2e-5
+        assert O.rel_l2(dw.cpu(), gw) < 2.4e-6 and O.rel_l2(db.cpu(), gb) < 2e-5
     from vitamd.lib import VitamdError
     with pytest.raises(VitamdError):
         ops.conv3x3_fwd(torch.zeros(1, 4, 8, 8, device="cuda"), torch.zeros(3, 4, 3, 3, device="cuda"), None)
@@ -464,7 +464,64 @@ def test_graphed_step_matches_eager(hip):
         loss_e = ce(m(xs[i]), ys[i]); loss_e.backward()
         assert abs(loss_g - float(loss_e)) < 1e-6
         for k, p in m.named_parameters():
-            assert O.rel_l2(got[k].cpu(), p.grad.cpu()) < 1e-5, k
+            assert O.rel_l2(got[k].cpu(), p.grad.cpu()) < 1.0e-6, k
     from vitamd.lib import VitamdError
     with pytest.raises(VitamdError):
         step(xs[0][:32], ys[0][:32])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 2: checks that do not pass through the oracle's kernel-shaped `lowp` emulation
+def test_vs_reference_own_bf16_autocast_outputs(hip):
+    """HIP path against the REFERENCE's own bf16-autocast tensors (tests/golden/ref_autocast_bf16.pt, written by
+    oracle/gen_golden.py from the unmodified reference under torch.autocast(cpu, bf16)).  Two independent bf16 flows of the same
+    fp32 function differ by about sqrt(2) x the bf16 floor of each, so the bound is 2 x the reference's recorded floor (its own
+    bf16-vs-fp32 distance) + a small constant; the measured values land in parity_errors.json."""
+    ref = load_golden("ref_autocast_bf16.pt")
+    for name in ("transformer_tiny", "transformer_layer_b"):
+        g = load_golden(name + ".pt")
+        floor = g["ref_bf16_floor"]
+        y, dx, grads, _, _ = _run_transformer(g)
+        r = ref[name]
+        if name == "transformer_tiny":
+            assert O.rel_l2(y, r["y"]) < 2 * floor["y"] + 1e-3
+            assert O.rel_l2(dx, r["dx"]) < 2 * floor["dx"] + 2e-3
+            for k, want in r["grads"].items():
+                assert O.rel_l2(grads[k], want) < 2 * floor["grads"][k] + 3e-3, k
+        else:
+            assert O.rel_l2(_sample(y), r["y"]["sample"]) < 2 * floor["y"] + 1e-3
+            assert O.rel_l2(_sample(dx), r["dx"]["sample"]) < 2 * floor["dx"] + 2e-3
+            for k, want in r["grads"].items():
+                assert _err(grads[k], want) < 2 * floor["grads"][k] + 4e-3, k
+    g = load_golden("vit_s32.pt")
+    floor = g["ref_bf16_floor"]
+    logits, loss, grads, _ = _run_classifier(g)
+    r = ref["vit_s32"]
+    assert O.rel_l2(logits, r["logits"]) < 2 * floor["logits"] + 2e-3
+    assert abs(loss - r["loss"]) < 2 * floor["loss_abs"] + 2e-3
+    for k, want in r["grads"].items():
+        assert _err(grads[k], want) < 2 * floor["grads"][k] + 5e-3, k
+
+
+def test_reference_loop_autocast_and_gradscaler_are_transparent(hip):
+    """The reference's loop runs the model under torch.autocast("cuda") (fp16) with a GradScaler (train_vit.py:84,100-106).
+    The modules own their precision flow (custom_fwd(cast_inputs=fp32)): logits must be IDENTICAL to the plain call, and the
+    unscaled gradients equal to it up to the exact power-of-two scale."""
+    import train_vit as TV
+    torch.manual_seed(3)
+    m = TV.ViTClassifier(TV.ViTConfig(32, 3, 16, "S", 1, 0.0), num_classes=10).cuda()
+    x, y = torch.randn(16, 3, 32, 32, device="cuda"), torch.randint(0, 10, (16,), device="cuda")
+    logits = m(x)
+    torch.nn.functional.cross_entropy(logits, y).backward()
+    plain = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    scaler = torch.amp.GradScaler("cuda")
+    with torch.autocast("cuda", dtype=torch.float16):
+        logits_amp = m(x)
+        loss_amp = torch.nn.functional.cross_entropy(logits_amp, y)
+    scaler.scale(loss_amp).backward()
+    scale = scaler.get_scale()
+    assert logits_amp.dtype == torch.float32 and torch.equal(logits_amp, logits)
+    for k, p in m.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        assert O.rel_l2((p.grad / scale).cpu(), plain[k].cpu()) < 1e-6, k

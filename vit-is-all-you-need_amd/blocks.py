@@ -282,16 +282,15 @@ class TiTokDecoder(nn.Module):
         self.conv_out = nn.Conv2d(3, 3, 3, padding=1, bias=True)
 
     def _tokens(self, z_quantized):
-        N, C, H, W = z_quantized.shape
-        assert H == 1 and W == self.num_latent_tokens, f"{H}, {W}, {self.num_latent_tokens}"
-        x = z_quantized.reshape(N, C * H, W).permute(0, 2, 1)  # NLD
-        x = linear(x, self.decoder_embed.weight, self.decoder_embed.bias)
-        seq_len = x.shape[1]
-        mask_tokens = self.mask_token.repeat(N, self.grid_size ** 2, 1).to(x.dtype)
-        mask_tokens = torch.cat([_expand_token(self.class_embedding, N).to(mask_tokens.dtype), mask_tokens], dim=1)
-        mask_tokens = mask_tokens + self.positional_embedding.to(mask_tokens.dtype)
-        x = x + self.latent_token_positional_embedding[:seq_len]
-        return torch.cat([mask_tokens, x], dim=1)
+        """decoder input sequence (reference blocks.py:336-348): [class token, grid^2 mask tokens] + positions, then the embedded
+        latent tokens + their own positions"""
+        batch, channels, one, n_latent = z_quantized.shape
+        assert one == 1 and n_latent == self.num_latent_tokens, f"{one}, {n_latent}, {self.num_latent_tokens}"
+        latents = linear(z_quantized.reshape(batch, channels, n_latent).transpose(1, 2), self.decoder_embed.weight, self.decoder_embed.bias)
+        latents = latents + self.latent_token_positional_embedding[:n_latent]
+        canvas = torch.cat([self.class_embedding.reshape(1, 1, -1), self.mask_token.expand(1, self.grid_size ** 2, -1)], dim=1)
+        canvas = (canvas + self.positional_embedding).to(latents.dtype).expand(batch, -1, -1)
+        return torch.cat([canvas, latents], dim=1)
 
     def _pixels(self, x):
         batchsize, g, p = x.shape[0], self.grid_size, self.patch_size
@@ -355,57 +354,52 @@ class VectorQuantizer(torch.nn.Module):
             self.decay = 0.99
             self.register_buffer("embed_prob", torch.zeros(self.codebook_size))
 
-    def forward(self, z: torch.Tensor) -> Tuple[torch.Tensor, Mapping[Text, torch.Tensor]]:
-        z = z.float().permute(0, 2, 3, 1).contiguous()                 # b c h w -> b h w c
-        z_flattened = z.reshape(-1, z.shape[-1])
-        unnormed_z_flattened = z_flattened
-        if self.use_l2_norm:
-            z_flattened = torch.nn.functional.normalize(z_flattened, dim=-1)
-            embedding = torch.nn.functional.normalize(self.embedding.weight, dim=-1)
-        else:
-            embedding = self.embedding.weight
-        zq, eq = z_flattened.detach().contiguous(), embedding.detach().float().contiguous()
-        min_encoding_indices = ops.vq_nearest(zq, eq)                  # argmin_k ||z - e_k||^2  (blocks.py:442-446)
-        z_quantized = self.get_codebook_entry(min_encoding_indices).view(z.shape)
-        if self.use_l2_norm:
-            z = torch.nn.functional.normalize(z, dim=-1)
+    # ---- pieces of the quantiser (behaviour of reference blocks.py:429-505) ----
+    def _unit(self, t):
+        """tokens / codes on the unit sphere when the quantiser is the cosine (l2-normalised) kind"""
+        return torch.nn.functional.normalize(t, dim=-1) if self.use_l2_norm else t
 
-        commitment_loss = self.commitment_cost * torch.mean((z_quantized.detach() - z) ** 2)
-        codebook_loss = torch.mean((z_quantized - z.detach()) ** 2)
-
-        if self.clustering_vq and self.training:
-            with torch.no_grad():
-                encoding_indices = gather(min_encoding_indices)
-                if len(min_encoding_indices.shape) != 1:
-                    raise ValueError(f"min_encoding_indices in a wrong shape, {min_encoding_indices.shape}")
-                # usage of each codebook entry
-                avg_probs = torch.bincount(encoding_indices, minlength=self.codebook_size).float() / encoding_indices.shape[0]
-                self.embed_prob.mul_(self.decay).add_(avg_probs, alpha=1 - self.decay)
-                # closest sampling: for every code the nearest (gathered) sample - the same kernel with the roles swapped
-                all_z = gather(zq)
-                all_unnormed_z_flattened = gather(unnormed_z_flattened).detach()
-                indices = ops.vq_nearest(eq, all_z)
-                random_feat = all_unnormed_z_flattened[indices]
-                decay = torch.exp(-(self.embed_prob * self.codebook_size * 10) / (1 - self.decay) - 1e-3).unsqueeze(1).repeat(1, self.token_size)
-                self.embedding.weight.data = self.embedding.weight.data * (1 - decay) + random_feat * decay
-
-        loss = commitment_loss + codebook_loss
-        z_quantized = z + (z_quantized - z).detach()                   # preserve gradients
-        z_quantized = z_quantized.permute(0, 3, 1, 2).contiguous()     # b h w c -> b c h w
-        result_dict = dict(
-            quantizer_loss=loss,
-            commitment_loss=commitment_loss,
-            codebook_loss=codebook_loss,
-            min_encoding_indices=min_encoding_indices.view(z_quantized.shape[0], z_quantized.shape[2], z_quantized.shape[3]))
-        return z_quantized, result_dict
+    def _lookup(self, codes_or_weights):
+        """hard lookup for integer code ids [T]; soft lookup (weights [T, K] times the codebook) for a float matrix"""
+        if codes_or_weights.dim() == 1:
+            return self.embedding(codes_or_weights)
+        if codes_or_weights.dim() == 2:
+            return codes_or_weights @ self.embedding.weight
+        raise NotImplementedError
 
     def get_codebook_entry(self, indices):
-        if len(indices.shape) == 1:
-            z_quantized = self.embedding(indices)
-        elif len(indices.shape) == 2:
-            z_quantized = torch.einsum('bd,dn->bn', indices, self.embedding.weight)
-        else:
-            raise NotImplementedError
-        if self.use_l2_norm:
-            z_quantized = torch.nn.functional.normalize(z_quantized, dim=-1)
-        return z_quantized
+        return self._unit(self._lookup(indices))
+
+    @torch.no_grad()
+    def _refresh_codebook(self, code_ids, tokens_unit, tokens_raw):
+        """clustering_vq (reference blocks.py:455-475): exponential usage statistics over the gathered batch, then every code is
+        pulled towards its nearest sample with a weight that is ~1 for codes nobody uses and ~0 for busy ones"""
+        if code_ids.dim() != 1:
+            raise ValueError(f"min_encoding_indices in a wrong shape, {code_ids.shape}")
+        ids_all = gather(code_ids)
+        usage = torch.bincount(ids_all, minlength=self.codebook_size).float() / ids_all.shape[0]
+        self.embed_prob.mul_(self.decay).add_(usage, alpha=1 - self.decay)
+        samples_unit, samples_raw = gather(tokens_unit), gather(tokens_raw).detach()
+        nearest_sample = ops.vq_nearest(self._unit(self.embedding.weight).detach().float().contiguous(), samples_unit)   # roles swapped
+        pull = torch.exp(-(self.embed_prob * self.codebook_size * 10) / (1 - self.decay) - 1e-3)[:, None].expand(-1, self.token_size)
+        self.embedding.weight.data = self.embedding.weight.data * (1 - pull) + samples_raw[nearest_sample] * pull
+
+    def forward(self, z: torch.Tensor) -> Tuple[torch.Tensor, Mapping[Text, torch.Tensor]]:
+        batch, _, rows, cols = z.shape
+        x = z.float().permute(0, 2, 3, 1)                                  # channels last: one token per (b, h, w)
+        tokens_raw = x.reshape(-1, x.shape[-1])
+        tokens = self._unit(tokens_raw)
+        tokens_c = tokens.detach().contiguous()
+        codes_c = self._unit(self.embedding.weight).detach().float().contiguous()
+        ids = ops.vq_nearest(tokens_c, codes_c)                            # argmin_k |token - code_k|^2 on the nearest-code kernel
+        target = tokens.view(x.shape)                                      # what the losses compare against (normalised if cosine)
+        picked = self.get_codebook_entry(ids).view(x.shape)
+        mse = lambda u, v: ((u - v) ** 2).mean()
+        commit = self.commitment_cost * mse(picked.detach(), target)
+        codebook = mse(picked, target.detach())
+        if self.clustering_vq and self.training:
+            self._refresh_codebook(ids, tokens_c, tokens_raw)
+        out = (target + (picked - target).detach()).permute(0, 3, 1, 2).contiguous()     # straight-through, back to b c h w
+        info = {"quantizer_loss": commit + codebook, "commitment_loss": commit, "codebook_loss": codebook,
+                "min_encoding_indices": ids.view(batch, rows, cols)}
+        return out, info

@@ -539,6 +539,7 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
     attr_done = true;
   }
   const bool use_ws = a.ws != nullptr && a.ws_bytes >= (size_t)splits * ntile * BP * BQ * sizeof(float);
+  if (!use_ws && !a.accumulate) return VITAMD_ERR_ARG;      // overwrite mode needs the workspace: the atomic form can only add to `out`
   const bool k16 = (g_vitamd_debug & 64) != 0;   // A/B knob: bit 6 selects the 16x16x32 variant (whole-step A/B: equal to the 32x32x16 form since its regrouping)
   if (use_ws) {
     if (k16) hipLaunchKernelGGL(gemm_tn16_kernel<true>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);

@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .functions import _amp_fwd, _amp_bwd
 from .functions import WEIGHTS, _f32c
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -21,6 +22,7 @@ class BlockFn(torch.autograd.Function):
     """x = x + proj(attn(LN1(x))) ; x = x + fc2(gelu(fc1(LN2(x))))   (reference blocks.py:62-70, 193-201)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, g1, be1, wqkv, bqkv, wo, bo, g2, be2, w1, b1, w2, b2, n_heads, has_mlp):
         B, N, D = x.shape
         H = n_heads
@@ -46,6 +48,7 @@ class BlockFn(torch.autograd.Function):
         return out.view(B, N, D).to(x.dtype)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         B, N, D, H, has_mlp, xdtype = ctx.meta
         g1p, wqkv, bqkv, wo, g2p, w1, w2 = ctx.params
@@ -95,6 +98,7 @@ class AttnProjFn(torch.autograd.Function):
     """proj(attention(qkv(x)))  — reference blocks.Attention (blocks.py:84-121), dropout-free."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, wqkv, bqkv, wo, bo, n_heads):
         B, N, D = x.shape
         xb = ops.cast_bf16(_f32c(x).view(B * N, D))
@@ -109,6 +113,7 @@ class AttnProjFn(torch.autograd.Function):
         return y.view(B, N, D).to(x.dtype)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         B, N, D, H, xdtype = ctx.meta
         wqkv, bqkv, wo = ctx.params
@@ -133,6 +138,7 @@ class MlpFn(torch.autograd.Function):
     """fc2(gelu(fc1(x)))  — reference blocks.Mlp (blocks.py:155-171), dropout-free."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w1, b1, w2, b2):
         lead, K = x.shape[:-1], x.shape[-1]
         xb = ops.cast_bf16(_f32c(x).reshape(-1, K))
@@ -146,6 +152,7 @@ class MlpFn(torch.autograd.Function):
         return y.view(*lead, w2.shape[0]).to(x.dtype)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         lead, K, xdtype = ctx.meta
         w1, w2 = ctx.params
@@ -171,6 +178,7 @@ class LayerNormAffineFn(torch.autograd.Function):
     320,326), whose input and output both live in the fp32 token stream."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, gamma, beta, eps):
         D = x.shape[-1]
         x2 = _f32c(x).reshape(-1, D)
@@ -180,6 +188,7 @@ class LayerNormAffineFn(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x2, mean, rstd, gamma = ctx.saved_tensors
         shape, xdtype = ctx.meta
@@ -193,6 +202,7 @@ class Conv3x3Fn(torch.autograd.Function):
     """nn.Conv2d(3, 3, 3, padding=1) on NCHW fp32 images (reference blocks.py:333 `conv_out`)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, b):
         xf, wf = _f32c(x), _f32c(w)
         y = ops.conv3x3_fwd(xf, wf, _f32c(b) if b is not None else None)
@@ -201,6 +211,7 @@ class Conv3x3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         xf, wf = ctx.saved_tensors
         dx, dw, db = ops.conv3x3_bwd(xf, wf, _f32c(g), need_dx=ctx.needs_input_grad[0], need_dw=True, has_bias=ctx.has_bias)

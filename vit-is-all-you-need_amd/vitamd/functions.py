@@ -13,6 +13,12 @@ from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
 
+# The reference's loops call the model under torch.autocast("cuda") with a GradScaler (train_vit.py:84,100-106).  Our Functions own their
+# precision flow (fp32 masters and residual stream, bf16 kernels): inside an autocast region every floating tensor argument is taken as
+# fp32 and autocast is switched off for the body, so the modules compute exactly what they compute outside of it.
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 class WeightCache:
     """bf16 (and transposed bf16) copies of fp32 parameters — autocast's per-step weight cast,
@@ -297,7 +303,25 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
     return g0, g0b
 
 
-_SIDE_KEEP = []     # tensors in use by side-stream work that the main stream has not been ordered behind yet
+_SIDE_KEEP = []     # tensors in use by side-stream work that the main stream has not been ordered behind yet (current layer)
+_SIDE_DONE = []     # (side-stream event, tensors) of finished layers, oldest first
+
+
+def side_checkpoint(device):
+    """Called after a layer's backward has been enqueued.  Marks the side stream's position and releases the operands of the layer
+    BEFORE this one: the main stream waits for that older mark (work enqueued a whole layer earlier - finished long ago in practice,
+    so the wait costs nothing and does not serialise the two streams), after which the allocator may hand those blocks out again.
+    Peak memory held for the side stream is two layers' operands instead of the whole stack's."""
+    if not SIDE.enabled:
+        _SIDE_KEEP.clear()
+        return
+    ev = torch.cuda.Event()
+    ev.record(SIDE.stream(device))
+    _SIDE_DONE.append((ev, list(_SIDE_KEEP)))
+    _SIDE_KEEP.clear()
+    while len(_SIDE_DONE) > 1:
+        old_ev, _ = _SIDE_DONE.pop(0)
+        torch.cuda.current_stream().wait_event(old_ev)
 
 
 def join_side(device):
@@ -307,10 +331,12 @@ def join_side(device):
         ev.record(SIDE.stream(device))
         torch.cuda.current_stream().wait_event(ev)
     _SIDE_KEEP.clear()
+    _SIDE_DONE.clear()
 
 
 class TransformerLayerFn(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, wqkv, bqkv, w1, b1, w2, b2, n_heads, causal, p_attn=0.0, p_mlp=0.0):
         B, N, D = x.shape
         need_grad = any(ctx.needs_input_grad)
@@ -324,6 +350,7 @@ class TransformerLayerFn(torch.autograd.Function):
         return x2.view(B, N, D).to(x.dtype)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         B, N, D, H, causal, xdtype = ctx.meta
         wqkv, w1, w2 = ctx.weights
@@ -339,6 +366,7 @@ class TransformerStackFn(torch.autograd.Function):
     i's fc2 weight/bias gradient, so no separate cast / column-sum passes exist between layers."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, n_heads, causal, p_attn, p_mlp, *params):
         B, N, D = x.shape
         L = len(params) // 6
@@ -361,6 +389,7 @@ class TransformerStackFn(torch.autograd.Function):
         return cur.view(B, N, D).to(x.dtype)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         B, N, D, H, causal, L, xdtype = ctx.meta
         saved_all = ctx.saved_tensors
@@ -369,17 +398,20 @@ class TransformerStackFn(torch.autograd.Function):
         cur = _f32c(g).view(B * N, D)
         arena, sink = grad_arena(D, L, cur.device, params)     # sink: the DDP wrapper whose buckets the arena lives in (or None)
         dy2 = None
-        for i in reversed(range(L)):
-            wqkv, _, w1, _, w2, _ = params[6 * i: 6 * i + 6]
-            nxt_db2 = arena[i - 1][5] if i > 0 else None      # layer i's first LN backward feeds layer i-1's fc2 bias grad
-            cur, dy2 = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal, arena[i],
-                                      dy2=dy2, have_db2=dy2 is not None, emit_bf16=i > 0, emit_colsum=nxt_db2,
-                                      drop=ctx.drops[i], emit_dropout=ctx.drops[i - 1][2:] if i > 0 else (0.0, 0))
-            if sink is not None:
-                # bucket i is complete now: five gradients from this call, and its fc2 bias gradient was
-                # added by layer i+1's LN1 backward (or by this call's own column sum for the top layer)
-                sink.layer_ready(params, i)
-        join_side(cur.device)
+        try:
+            for i in reversed(range(L)):
+                wqkv, _, w1, _, w2, _ = params[6 * i: 6 * i + 6]
+                nxt_db2 = arena[i - 1][5] if i > 0 else None      # layer i's first LN backward feeds layer i-1's fc2 bias grad
+                cur, dy2 = layer_backward(cur, saved_all[n_saved * i: n_saved * (i + 1)], wqkv, w1, w2, B, N, H, causal, arena[i],
+                                          dy2=dy2, have_db2=dy2 is not None, emit_bf16=i > 0, emit_colsum=nxt_db2,
+                                          drop=ctx.drops[i], emit_dropout=ctx.drops[i - 1][2:] if i > 0 else (0.0, 0))
+                if sink is not None:
+                    # bucket i is complete now: five gradients from this call, and its fc2 bias gradient was
+                    # added by layer i+1's LN1 backward (or by this call's own column sum for the top layer)
+                    sink.layer_ready(params, i)
+                side_checkpoint(cur.device)
+        finally:
+            join_side(cur.device)       # also on an exception: nothing stays pinned for the side stream
         grads = [t for layer in arena for t in layer]
         return (cur.view(B, N, D).to(xdtype), None, None, None, None, *grads)
 
@@ -389,6 +421,7 @@ class TransformerStackFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class AttentionFn(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, wqkv, bqkv, n_heads, causal, p_attn=0.0):
         B, N, D = x.shape
         need_grad = any(ctx.needs_input_grad)
@@ -404,6 +437,7 @@ class AttentionFn(torch.autograd.Function):
         return o.view(B, N, D).to(x.dtype)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         B, N, D, H, causal, xdtype = ctx.meta
         xb, qkv, o, lse = ctx.saved_tensors
@@ -422,6 +456,7 @@ class AttentionFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class PatchEmbedFn(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, images, conv_w, conv_b, pos_w, extra_w, patch, n_patches):
         B = images.shape[0]
         D = conv_w.shape[0]
@@ -445,6 +480,7 @@ class PatchEmbedFn(torch.autograd.Function):
         return x
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         B, D, extra, seq, n_patches, wshape, pos_rows, ishape, patch = ctx.meta
         (patches,) = ctx.saved_tensors
@@ -483,6 +519,7 @@ class LinearFn(torch.autograd.Function):
     input dim likewise (reduction dim of the forward GEMM).  x: [M, K] -> [M, Nout] fp32."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, b):
         M, K = x.shape
         Nout = w.shape[0]
@@ -506,6 +543,7 @@ class LinearFn(torch.autograd.Function):
         return y[:, :Nout].to(F32)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         M, K, Kp, Nout, Np, xdtype, has_b = ctx.meta
         xb, wbt = ctx.saved_tensors

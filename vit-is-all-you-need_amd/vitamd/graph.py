@@ -27,7 +27,7 @@ class GraphedStep:
         if not example_x.is_cuda:
             raise F.ops._lib.VitamdError("GraphedStep needs device tensors (there is no CPU path)")
         for m in model.modules():
-            if float(getattr(m, "dropout", 0.0) or 0.0) > 0.0 and m.training:
+            if float(getattr(m, "dropout", 0.0) or 0.0) > 0.0:      # attention dropout is applied in eval() too (reference transformer.py:28)
                 raise NotImplementedError("GraphedStep with dropout > 0: the mask seed would be frozen into the graph")
         self.model, self.loss_fn = model, loss_fn
         self.x = example_x.detach().clone()
