@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 import train_vit as TV
 from vitamd import functions as F, lib
-L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+lib.use_experimental(); L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
 cfgs = {"production": 0}
 for a in sys.argv[1:]:
     k, v = a.split("="); cfgs[k] = int(v, 0)

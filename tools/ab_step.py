@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 import train_vit as TV
 from vitamd import lib, functions as F
-L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+lib.use_experimental(); L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = TV.ViTClassifier(TV.ViTConfig(224, 3, 16, "B", 1, 0.0)).to(dev)

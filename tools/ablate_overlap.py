@@ -3,7 +3,7 @@ import os, sys, torch, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops, lib
-L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+lib.use_experimental(); L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
 dev = torch.device("cuda")
 M, D = 256 * 197, 768
 g = torch.Generator(device="cpu").manual_seed(0)

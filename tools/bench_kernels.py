@@ -10,6 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops  # noqa: E402
+from vitamd import lib as _explib; _explib.use_experimental()
 
 BF16 = torch.bfloat16
 dev = torch.device("cuda")

@@ -5,6 +5,7 @@ import os, sys, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops
+from vitamd import lib as _explib; _explib.use_experimental()
 cfgs = {"r1_pipe": 0, "pp256_4_6": 7, "pp320_4_6": 8, "pp320_6_6": 9}
 for a in sys.argv[1:]:
     k, v = a.split("="); cfgs[k] = int(v, 0)

@@ -3,9 +3,14 @@ import os, sys, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops
+import ctypes
+from vitamd import lib
+lib.use_experimental(); L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
 cfgs = {}
-for a in sys.argv[1:]:
-    k, v = a.split("="); cfgs[k] = int(v, 0)
+for a in sys.argv[1:]:                      # name=tile[:dbgbits]
+    k, v = a.split("=")
+    t, _, d = v.partition(":")
+    cfgs[k] = (int(t, 0), int(d, 0) if d else 0)
 dev = torch.device("cuda")
 M = 256 * 197
 g = torch.Generator(device="cpu").manual_seed(1)
@@ -16,7 +21,8 @@ for (N, K) in [(2304, 768), (3072, 768), (768, 2304), (768, 3072)]:
     ref = None
     res = {k: [] for k in cfgs}
     for rnd in range(5):
-        for k, t in cfgs.items():
+        for k, (t, dbg) in cfgs.items():
+            L.vitamd_set_debug(dbg)
             out = ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, tile=t)
             if rnd == 0:
                 torch.cuda.synchronize()
@@ -28,6 +34,7 @@ for (N, K) in [(2304, 768), (3072, 768), (768, 2304), (768, 3072)]:
             for _ in range(10): ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, tile=t)
             e.record(); torch.cuda.synchronize()
             res[k].append(s.elapsed_time(e) / 10 * 1e3)
+    L.vitamd_set_debug(0)
     fl = 2.0 * M * N * K
     for k in cfgs:
         med = statistics.median(res[k]); tot[k] += med

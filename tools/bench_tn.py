@@ -4,7 +4,7 @@ import os, sys, statistics, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops, lib
-L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+lib.use_experimental(); L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
 cfgs = {"r1_vgpr_staged": 6 << 26, "pp_d4": 0, "pp_d6": 7 << 26}
 for a in sys.argv[1:]:
     k, v = a.split("="); cfgs[k] = int(v, 0)

@@ -3,6 +3,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops
+from vitamd import lib as _explib; _explib.use_experimental()
 dev = torch.device("cuda")
 M = 256 * 197
 def t(fn, n=10):

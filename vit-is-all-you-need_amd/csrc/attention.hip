@@ -17,7 +17,6 @@
 //   bwd dKV : lane = key.    S = Q.K^T ; dP = dO.V^T ; dV^T += dO^T.P ; dK^T += Q^T.dS
 // Scores are recomputed from Q, K and the forward's log-sum-exp (flash-attention backward).
 #include "common.h"
-extern int g_vitamd_debug;
 
 namespace {
 
@@ -532,175 +531,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
   }
 }
 
-// ------------------------------------------------------------------------------------------ backward, fused (N <= 256)
-// dQ, dK and dV of one (batch, head) in ONE pass: S and dP are computed once per 32x32 tile (5 MFMA products per tile instead of
-// the 7 of the two kernels above, one exp instead of two) and q, k, v, dO are read from HBM once (618 MB instead of 926 MB per
-// layer at the headline shape).  One workgroup of 8 waves per (batch, head); wave w owns KEY block w (dK_w, dV_w accumulate in its
-// registers, key on the lane, as in attn_bwd_dkv_kernel) AND QUERY block w (dQ_w accumulates in its registers, query on the lane, as
-// in attn_bwd_dq_kernel).  Step t of nt: wave w works on the tile (query block (w + t) % nt, key block w): S, dP, P, dS, dV += dO^T P,
-// dK += Q^T dS, then hands bf16(dS) to the owner of that query block through a 2-KiB LDS slot ([key][query] image, written as four
-// 8-B pieces per lane, read back with ds_read_b64_tr_b16 as the B operand of dQ^T += K^T dS^T); two barriers per step.
-// LDS: Q, dO, K tiles of the head (K only for the transposed reads of the dQ product; V and the key-block's K live in registers).
-constexpr int FUSED_MAX_NT = 8;
-
-// A-operand fragment by TRANSPOSED read in NATURAL k order: element j = Y[32T + 16s + 8(lane>>5) + j][32dt + (lane&31)]
-__device__ __forceinline__ bf16x8 tr_frag_nat(const char* tile, int T, int s, int dt, int lane) {
-  const int h = lane >> 5, colhalf = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
-  const int chunk = 4 * dt + 2 * colhalf + (pp >> 1);
-  bf16x4 part[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int rloc = 16 * s + 8 * h + 4 * u + qq;   // row inside the 32-row tile
-    part[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + T * 4096 + rloc * 128 + ((chunk ^ swz(rloc)) << 4) + (pp & 1) * 8));
-  }
-  return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// exchange slot: [32 keys][32 queries] bf16, 64-B rows, 8-B piece index (query/4) XOR ((key>>1)&7): conflict-free writes and reads
-__device__ __forceinline__ int xch_off(int key, int qslot) { return key * 64 + ((qslot ^ ((key >> 1) & 7)) << 3); }
-
-template <bool DROP>
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
-  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
-  const int nt = (N + 31) / 32, npad = nt * 32;
-  char* qtile = smem;
-  char* dotile = smem + npad * 128;
-  char* ktile = smem + 2 * npad * 128;
-  float* lse_s = (float*)(smem + 3 * npad * 128);
-  float* delta_s = lse_s + npad;
-  char* xch = smem + 3 * npad * 128 + 2 * npad * 4;          // 8 slots x 2 KiB
-  char* oimg = xch + 8 * 2048 + wave * 4096;                  // wave-private store image
-  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
-  const __bf16* obase = a.o + (size_t)b * N * D + hh * DH;
-  const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
-  stage_tile(qbase, D3, N, npad, qtile, wave, lane, 8);
-  stage_tile(dobase, D, N, npad, dotile, wave, lane, 8);
-  stage_tile(qbase + D, D3, N, npad, ktile, wave, lane, 8);
-  const bool active = wave < nt;
-  const int k0 = wave * 32, krow = k0 + (lane & 31);           // this wave's key block = its query block
-  bf16x8 kf[4], vf[4];
-  if (active) {
-    load_lane_frags(qbase + D, D3, N, k0, lane, kf);
-    load_lane_frags(qbase + 2 * D, D3, N, k0, lane, vf);
-    // delta = rowsum(dO o O) and the forward's log-sum-exp of this wave's QUERY block -> LDS
-    bf16x8 dof[4], of[4];
-    load_lane_frags(dobase, D, N, k0, lane, dof);
-    load_lane_frags(obase, D, N, k0, lane, of);
-    float delta = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) delta += (float)dof[kk][j] * (float)of[kk][j];
-    delta += __shfl_xor(delta, 32, 64);
-    if (lane < 32) {
-      delta_s[krow] = delta;
-      lse_s[krow] = a.lse2[((size_t)b * a.H + hh) * N + min(krow, N - 1)];
-      if (krow < N) a.delta[((size_t)b * a.H + hh) * N + krow] = delta;     // kept for callers that inspect it
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const float c = a.scale_log2e;
-  f32x16 dk[2], dv[2], dq[2];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; dq[dt][r] = 0.f; }
-  const int h = lane >> 5, colhalf = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
-  char* myslot = xch + wave * 2048;
-
-  const int nsteps = (a.causal & 2) ? 0 : ((a.causal & 4) ? 1 : nt);   // timing-only ablations ride in bits 1,2 of `causal` (launcher: dbg bits 10, 11)
-  for (int t = 0; t < nsteps; ++t) {
-    // ---- producer half: tile (query block T, key block wave)
-    int T = wave + t;
-    if (T >= nt) T -= nt;
-    const bool do_tile = active && (!(a.causal & 1) || T >= wave);       // queries before the key block never attend to it
-    if (do_tile) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, T, kk, lane), kf[kk], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, T, kk, lane), vf[kk], dp, 0, 0, 0);
-      }
-      f32x16 pmat;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int qr = 32 * T + 8 * u + 4 * h;
-        const f32x4 lse4 = *(const f32x4*)(lse_s + qr);
-        const f32x4 del4 = *(const f32x4*)(delta_s + qr);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * u + i;
-          const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse4[i]));
-          float keep = 1.0f;
-          if constexpr (DROP) keep = attn_keep(a, blockIdx.x, min(qr + i, N - 1), min(krow, N - 1));
-          pmat[r] = pexp * keep;
-          s[r] = pexp * (dp[r] * keep - del4[i]);
-        }
-        if (32 * T + 32 > N || k0 + 32 > N || ((a.causal & 1) && T == wave)) {   // boundary tiles only (wave-uniform)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 4 * u + i, query = qr + i;
-            if (!(query < N && krow < N && (!(a.causal & 1) || krow <= query))) { pmat[r] = 0.f; s[r] = 0.f; }
-          }
-        }
-        // dS piece: queries 8u + 4h .. +3 of key (lane&31)
-        u32x2 piece = {pack_bf16x2(s[4 * u], s[4 * u + 1]), pack_bf16x2(s[4 * u + 2], s[4 * u + 3])};
-        *(u32x2*)(myslot + xch_off(lane & 31, 2 * u + h)) = piece;
-      }
-#pragma unroll
-      for (int sidx = 0; sidx < 2; ++sidx) {
-        const bf16x8 pf = acc_to_frag(pmat, sidx);
-        const bf16x8 dsf = acc_to_frag(s, sidx);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dotile, T, sidx, dt, lane), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, T, sidx, dt, lane), dsf, dk[dt], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();                                    // every dS tile of this step is in its slot
-    // ---- consumer half: this wave's QUERY block (= wave) against key block J, produced this step by wave J
-    int J = wave - t;
-    if (J < 0) J += nt;
-    if (active && (!(a.causal & 1) || wave >= J)) {
-      const char* slot = xch + J * 2048;
-#pragma unroll
-      for (int sidx = 0; sidx < 2; ++sidx) {
-        // B[k = key 16 sidx + 8h + j][n = query 16 colhalf + (lane&15)]: two transposed reads of 4 keys x 16 queries
-        bf16x4 part[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int key = 16 * sidx + 8 * h + 4 * u + qq;
-          part[u] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(slot + xch_off(key, 4 * colhalf + pp)));
-        }
-        const bf16x8 dsf = __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_nat(ktile, J, sidx, dt, lane), dsf, dq[dt], 0, 0, 0);
-      }
-    }
-    __syncthreads();                                    // slots free for the next step
-  }
-  if (active) {
-    __bf16* dbase = a.dqkv + (size_t)b * N * D3 + hh * DH;
-    float csum_q = 0.f, csum_k = 0.f, csum_v = 0.f;
-    store_rows_T_lds(dbase, D3, N, k0, lane, dq, a.scale, oimg, a.dbias ? &csum_q : nullptr);
-    store_rows_T_lds(dbase + D, D3, N, k0, lane, dk, a.scale, oimg, a.dbias ? &csum_k : nullptr);
-    store_rows_T_lds(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f, oimg, a.dbias ? &csum_v : nullptr);
-    if (a.dbias) {
-      atomicAdd(a.dbias + hh * DH + lane, csum_q);
-      atomicAdd(a.dbias + D + hh * DH + lane, csum_k);
-      atomicAdd(a.dbias + 2 * D + hh * DH + lane, csum_v);
-    }
-  }
-}
+#ifdef VITAMD_EXPERIMENTAL
+#include "experimental/attention_fused.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------ long sequences (N > 512)
 // Same three algorithms with both sides tiled: the grid gets a second dimension over blocks of 128 "lane-side" rows
@@ -977,11 +810,6 @@ int check(const AttnArgs& a) {
   return VITAMD_OK;
 }
 
-template <typename K>
-int set_lds(K kern, int bytes) {
-  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
-}
-
 }  // namespace
 
 static bool attn_dropout(AttnArgs& a, float p, unsigned long long seed) {
@@ -1090,9 +918,10 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
     return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
   }
   const int npad = (N + 31) / 32 * 32;
+#ifdef VITAMD_EXPERIMENTAL
   if (npad <= 32 * FUSED_MAX_NT && (g_vitamd_debug & 0x200)) {      // dbg bit 9: the one-pass fused kernel (measured: 290 us against 265 us for the two kernels at B=256, N=197, H=12 - its load/store phase (147 us) and its lock-stepped compute (142 us) do not overlap with one workgroup per CU)
     const int ldsf = 3 * npad * 128 + 2 * npad * 4 + 8 * 2048 + 8 * 4096;
-    a.causal = (causal ? 1 : 0) | ((g_vitamd_debug >> 9) & 6);
+    a.causal = (causal ? 1 : 0) | ((g_vitamd_debug >> 9) & 14);
     if (a.drop_thresh) {
       if (int e = set_lds(attn_bwd_fused_kernel<true>, ldsf)) return e;
       hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(B * H), dim3(512), ldsf, stream, a);
@@ -1102,6 +931,7 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
     }
     return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
   }
+#endif
   const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
   if (a.drop_thresh) {
     if (int e = set_lds(attn_bwd_dq_kernel<true>, lds1)) return e;

@@ -5,15 +5,17 @@
 
 extern "C" int vitamd_abi_version(void) { return 4; }
 
+#ifdef VITAMD_EXPERIMENTAL
 int g_vitamd_debug = 0;
-// Diagnostics knob for the A/B tools (tools/ab_dbg.py, tools/ablate_*.py); process-global, 0 in production, NOT in the public
-// header.  Bits marked (!) make results wrong (timing only).
-//   NT GEMM : 0 skip gelu math(!)   1 skip 2nd GELU store(!)   2 skip residual load(!)   3 plain (temporal) output stores
-//             4 tail split for every GEMM   5 plain tile order   7 no fc2-forward tail split   8-15 stagger unit in ~us (255 = off)
-//             16 no output stores(!)   17 one K-tile only(!)   19 no 320-row tiles   20-23 stagger phases   24 stagger map
-//             29 stage through VGPRs instead of LDS-DMA
-//   TN GEMM : 6 16x16x32 form   25 256x384-tile kernel (gemm_tn_wide.hip)   26-28: 1 no MFMA(!) 2 no loads(!) 3 no LDS reads(!) 5 LDS-DMA staging
+// Diagnostics knob of the EXPERIMENTAL library only (libvitamd_exp.so: tools/ab_*.py, tools/ablate_*.py); process-global, not in the
+// public header, absent from the production library.  Bits marked (!) make results wrong (timing only).
+//   NT GEMM : 2 every tile stores to the same rows(!)   3 plain (temporal) output stores   4 tail split for every GEMM   7 no fc2-forward
+//             tail split   16 no output stores(!)   18 every tile loads L2-resident panels(!)   19 no 320-row tiles   29 pipe kernel staged
+//             through VGPRs   30 the round-1 pipe kernel instead of the ping-pong kernel
+//   TN GEMM : 6 round-1 16x16x32 form   25 256x384-tile kernel   26-28: 1-3 round-1 timing ablations(!), 5 round-1 LDS-DMA, 6 round-1 VGPR-staged, 7 ping-pong D = 6
+//   attention: 9 one-pass fused backward   10-12 its timing probes(!)
 extern "C" int vitamd_set_debug(int bits) { g_vitamd_debug = bits; return 0; }
+#endif
 
 extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
                                    float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
@@ -22,8 +24,12 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
   const int dg = (epi == 6 || epi == 7) ? 1 : 0;
   if (epi == 6) epi = EPI_GELU;
   if (epi == 7) epi = EPI_DGELU;
-  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, g_vitamd_debug, 0u, 1.0f, 0u, 0u, 0, dg};
-  if (!(tile >= 0 && tile <= 19) && tile != 128 && tile != 256 && (tile < 21 || tile > 24)) return VITAMD_ERR_ARG;
+  GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, VITAMD_GDBG, 0u, 1.0f, 0u, 0u, 0, dg};
+  #ifdef VITAMD_EXPERIMENTAL
+  if (!(tile >= 0 && tile <= 24) && tile != 128 && tile != 256 && tile != 257 && tile != 320) return VITAMD_ERR_ARG;
+#else
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 320) return VITAMD_ERR_ARG;
+#endif
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }
 
@@ -50,7 +56,7 @@ static bool dropout_params(float p, unsigned& thresh, float& scale) {
 // fc2 with dropout: out f32 = resid + dropout_p(bf16(A.B^T + bias)) — reference transformer.py:39-40,44
 extern "C" int vitamd_linear_dropout_resid_bf16(const void* A, const void* B, float* out, const float* bias, const float* resid,
                                                 int M, int N, int K, float dropout_p, unsigned long long seed, void* stream) {
-  GemmNtArgs p{A, B, out, nullptr, bias, resid, nullptr, M, N, K, N, EPI_RESID_F32, 0, 0, 0, 0, g_vitamd_debug, 0u, 1.0f,
+  GemmNtArgs p{A, B, out, nullptr, bias, resid, nullptr, M, N, K, N, EPI_RESID_F32, 0, 0, 0, 0, VITAMD_GDBG, 0u, 1.0f,
                (unsigned)seed, (unsigned)(seed >> 32), 0, 0};
   if (!dropout_params(dropout_p, p.drop_thresh, p.drop_scale)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);

@@ -13,6 +13,17 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+// Timing-only / A-B debug knobs exist only in experimental builds (`make EXPERIMENTAL=1` -> libvitamd_exp.so); in the production
+// library every knob reads as the constant 0 and the code behind it is compiled out.
+#ifdef VITAMD_EXPERIMENTAL
+extern int g_vitamd_debug;
+#define VITAMD_DBG(p) ((p).dbg)
+#define VITAMD_GDBG g_vitamd_debug
+#else
+#define VITAMD_DBG(p) 0
+#define VITAMD_GDBG 0
+#endif
+
 #define VITAMD_OK 0
 #define VITAMD_ERR_SHAPE 1
 #define VITAMD_ERR_ARG 2
@@ -72,6 +83,12 @@ __device__ __forceinline__ void asm_glds16(srd_t srd, unsigned lds_dst, unsigned
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
+// dynamic-LDS opt-in for a kernel; called on every launch (a cheap host call) so it holds for whichever device is current
+template <typename K>
+static inline int set_lds(K kern, int bytes) {
+  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
 // erf with |abs err| < 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_exp, one v_rcp, 5 fma.

@@ -16,8 +16,8 @@
 // no 1-KiB piece crosses a row; 16-B chunk c of row r stored at c ^ ((r&3)<<2), closed inside aligned groups of
 // 16 chunks; all row strides are multiples of the 256-B bank period, so the transposed reads stay conflict-free
 // as in gemm_tn.hip), fragments come from ds_read_b64_tr_b16.  8 waves (2 x 4), wave tile 128 x 96.
-#include "common.h"
-#include "vitamd_internal.h"
+#include "../common.h"
+#include "../vitamd_internal.h"
 
 namespace {
 

@@ -3,17 +3,13 @@
 //   reference transformer.py:21,37,39 and of the patch-embed conv train_vit.py:34).
 //
 // Both operands are stored with the REDUCTION index as the slow (row) dimension, so neither is
-// MFMA-fragment shaped in memory.  gfx950 answer: stage [64 r][256 cols] tiles row-major (whole 512-B
-// rows, zero-fill past the last row through the buffer descriptor's range check) and read the fragments
-// with the hardware transpose read ds_read_b64_tr_b16.  Staging is buffer_load -> VGPR -> ds_write_b128
-// (issued group by group under the MFMAs of the current stage, written at its end); the LDS-DMA form
-// (buffer_load ... lds, same addresses, same LDS image) is kept behind dbg bits 26-28 = 5: ablations show this
-// kernel is bound by operand delivery (removing every MFMA: 310 -> 296 us) and the register path
-// delivers ~6 % faster here, while the NT kernel prefers LDS-DMA (tools/ablate_tn.py, tools/ab_dbg.py).  The 16-B
-// chunk index of row r is XOR-ed with (r&3)<<2 (on the global source side) which makes every
-// transposed read bank-conflict-free (tools/lds_banks.py).  mfma_f32_32x32x16_bf16 so one accumulator
-// register of a wave = two 128-B row segments: the shape float atomics run at full rate with.
-// Split over the reduction dimension (grid = tiles x splits) with fp32 atomic accumulation.
+// MFMA-fragment shaped in memory.  gfx950 answer: stage whole 512-B rows of [r][256 cols] tiles by LDS-DMA (zero-fill past the last
+// row through the buffer descriptor's range check) and read the fragments with the hardware transpose read ds_read_b64_tr_b16.
+// The 16-B chunk index of row r is XOR-ed with (r&3)<<2 (on the global source side) which makes every transposed read
+// bank-conflict-free (tools/lds_banks.py).  mfma_f32_32x32x16_bf16 so one accumulator register of a wave = two 128-B row segments:
+// the shape float atomics run at full rate with.  Split over the reduction dimension (grid = tiles x splits): partial tiles go to a
+// workspace with plain stores and a reduce pass sums them (bitwise reproducible), or fp32 atomics straight into `out`.
+// The production kernel is the ping-pong kernel below; the round-1 kernels are in experimental/gemm_tn_variants.inc.
 #include "common.h"
 #include "vitamd_internal.h"
 
@@ -35,289 +31,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
   bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
   bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 4 * 512));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-template <bool WS, int ABL = 0>   // ABL: timing-only ablations (1 = no MFMA, 2 = no LDS-DMA, 3 = no transposed reads: results are garbage); 4 = stage through VGPRs + ds_write instead of LDS-DMA (correct results)
-__global__ __launch_bounds__(NW * 64) void gemm_tn_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave / WQ, wq = wave % WQ;
-
-  const int ntile = tiles_p * tiles_q;
-  const int id = xcd_remap(blockIdx.x, ntile * splits);
-  const int split = id / ntile, tile = id % ntile;
-  const int p0 = (tile / tiles_q) * BP, q0 = (tile % tiles_q) * BQ;
-
-  // reduction range of this split, in BR-row steps
-  const int nsteps = (a.R + BR - 1) / BR;
-  const int s_lo = (int)((long)nsteps * split / splits), s_hi = (int)((long)nsteps * (split + 1) / splits);
-  if (s_lo >= s_hi) return;
-
-  const __amdgpu_buffer_rsrc_t rsrcL = make_rsrc(a.L, (size_t)a.R * a.ldl * 2);
-  const __amdgpu_buffer_rsrc_t rsrcR = make_rsrc(a.Rm, (size_t)a.R * a.ldr * 2);
-
-  // this wave's pieces: waves 0-3 stage L rows, waves 4-7 stage R rows (16 rows each per stage).
-  // Rows past R and columns past the matrix edge must read as ZERO (they enter the reduction): rows
-  // fall out of the descriptor's range by themselves, edge columns get an offset of 2 GiB (buffers
-  // are < 2 GiB, checked on the host; the per-step byte offset rides in the scalar offset).
-  const bool isL = wave < NW / 2;
-  const int ld = isL ? a.ldl : a.ldr;
-  const int c0 = isL ? p0 : q0;
-  const int ncols = isL ? a.P : a.Q;
-  const __amdgpu_buffer_rsrc_t rsrc = isL ? rsrcL : rsrcR;
-  unsigned voff[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int row = ((wave & 3) * PPW + i) * 2 + (lane >> 5);
-    const int logical = (lane & 31) ^ ((row & 3) << 2);
-    const int col = c0 + logical * 8;
-    voff[i] = (col < ncols) ? (unsigned)(((size_t)row * ld + col) * 2) : 0x80000000u;
-  }
-  const unsigned step_bytes = (unsigned)BR * ld * 2;
-  char* const stage_base = smem + (isL ? 0 : TILE_BYTES) + (wave & 3) * PPW * 1024;
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // transposed-read lane addressing (see header): within a 16-lane group lane 4*qq+pp supplies
-  // row qq, columns 4pp..4pp+3 of a 4x16 block; group = (k-half h = lane>>5, column half = (lane>>4)&1)
-  const int h = lane >> 5, colhalf = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
-  const int rowpart = (8 * h + qq) * 512 + (pp & 1) * 8;
-  int offA[MT], offB[NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int chunk = (wp * (BP / WP) + i * 32) / 8 + 2 * colhalf + (pp >> 1);
-    offA[i] = rowpart + ((chunk ^ (qq << 2)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int chunk = (wq * (BQ / WQ) + j * 32) / 8 + 2 * colhalf + (pp >> 1);
-    offB[j] = TILE_BYTES + rowpart + ((chunk ^ (qq << 2)) << 4);
-  }
-
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) buf_glds16(rsrc, stage_base + i * 1024, voff[i], s_lo * step_bytes);
-  for (int s = s_lo; s < s_hi; ++s) {
-    const int cur = (s - s_lo) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const char* buf = smem + cur * BUF_BYTES;
-    char* nbase = stage_base + (cur ^ 1) * BUF_BYTES;
-    const bool more = s + 1 < s_hi;
-    const int soff = (s + 1) * step_bytes;
-    // four 16-deep groups of 8 MFMAs; each first issues two DMA pieces of the next stage and the
-    // transposed reads of the NEXT group's fragments (register double buffer), then its MFMAs
-    bf16x8 af[2][MT], bfr[2][NT];
-    u32x4 stg[ABL == 4 ? PPW : 1];
-    if (ABL != 3 || s == s_lo) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[0][j] = tr_frag(buf + offB[j]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[0][i] = tr_frag(buf + offA[i]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < BR / 16; ++ks) {
-      if (more && ABL != 2) {
-        if constexpr (ABL == 4) {
-          stg[2 * ks] = buf_load16(rsrc, voff[2 * ks], soff);
-          stg[2 * ks + 1] = buf_load16(rsrc, voff[2 * ks + 1], soff);
-        } else {
-          buf_glds16(rsrc, nbase + (2 * ks) * 1024, voff[2 * ks], soff);
-          buf_glds16(rsrc, nbase + (2 * ks + 1) * 1024, voff[2 * ks + 1], soff);
-        }
-      }
-      if (ks + 1 < BR / 16 && (ABL != 3 || s == s_lo)) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bfr[(ks + 1) & 1][j] = tr_frag(buf + offB[j] + (ks + 1) * 16 * 512);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[(ks + 1) & 1][i] = tr_frag(buf + offA[i] + (ks + 1) * 16 * 512);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          if constexpr (ABL == 1) { asm volatile("" ::"v"(af[ks & 1][i]), "v"(bfr[ks & 1][j])); }
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (ABL == 4) {
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) *(u32x4*)(nbase + i * 1024 + lane * 16) = stg[i];
-      }
-    }
-  }
-
-  // D[i = p][j = q]: col q = lane&31, row p = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  if constexpr (WS) {
-    // partial tile -> workspace with plain stores (one accumulator register = two 128-B row
-    // segments); the reduce pass sums the splits.  ~4-5x the rate of fp32 atomics.
-    float* wt = a.ws + ((size_t)split * ntile + tile) * (BP * BQ);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int ql = wq * (BQ / WQ) + j * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int pl = wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) wt[(pl + (r & 3) + 8 * (r >> 2)) * BQ + ql] = acc[i][j][r];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int q = q0 + wq * (BQ / WQ) + j * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int pbase = p0 + wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int p = pbase + (r & 3) + 8 * (r >> 2);
-          if (p < a.P && q < a.Q) atomicAdd(a.out + (size_t)p * a.ldo + q, acc[i][j][r]);
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Same GEMM on mfma_f32_16x16x32_bf16 with the operands swapped so a lane owns 4 consecutive q of one output row
-// (16-B stores / 4 atomics per 16x16 tile).  Swizzle f(r) = ((r&3)<<2) | (((r>>3)&1)<<1) keeps the transposed reads
-// conflict-free for this operand shape (tools/lds_banks.py "TN16"; SQ_LDS_BANK_CONFLICT = 0 measured).
-// History worth keeping: with the NT kernel's grouping (8 groups of 8 MFMAs = 128 MFMA cycles each, next group's
-// fragments read one group ahead) this kernel ran 1.55x SLOWER than the 32x32x16 form - waves parked on the LDS waits
-// (SQ_WAIT_ANY 80 % of wave cycles): a fragment here is TWO transposed reads, and 128 cycles do not cover them.
-// Four groups of 16 MFMAs (256 cycles) + the VGPR staging path bring it level with the 32x32x16 kernel (whole-step
-// A/B 34.47 vs 34.47 ms); it stays an alternative (vitamd_set_debug bit 6), the 32x32x16 form needs 24 fewer VGPRs.
-template <bool WS>
-__global__ __launch_bounds__(NW * 64) void gemm_tn16_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wave / WQ, wq = wave % WQ;
-  const int ntile = tiles_p * tiles_q;
-  const int id = xcd_remap(blockIdx.x, ntile * splits);
-  const int split = id / ntile, tile = id % ntile;
-  const int p0 = (tile / tiles_q) * BP, q0 = (tile % tiles_q) * BQ;
-  const int nsteps = (a.R + BR - 1) / BR;
-  const int s_lo = (int)((long)nsteps * split / splits), s_hi = (int)((long)nsteps * (split + 1) / splits);
-  if (s_lo >= s_hi) return;
-
-  const __amdgpu_buffer_rsrc_t rsrcL = make_rsrc(a.L, (size_t)a.R * a.ldl * 2);
-  const __amdgpu_buffer_rsrc_t rsrcR = make_rsrc(a.Rm, (size_t)a.R * a.ldr * 2);
-  const bool isL = wave < NW / 2;
-  const int ld = isL ? a.ldl : a.ldr;
-  const int c0 = isL ? p0 : q0;
-  const int ncols = isL ? a.P : a.Q;
-  const __amdgpu_buffer_rsrc_t rsrc = isL ? rsrcL : rsrcR;
-  unsigned voff[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int row = ((wave & 3) * PPW + i) * 2 + (lane >> 5);
-    const int f = ((row & 3) << 2) | (((row >> 3) & 1) << 1);
-    const int col = c0 + ((lane & 31) ^ f) * 8;
-    voff[i] = (col < ncols) ? (unsigned)(((size_t)row * ld + col) * 2) : 0x80000000u;
-  }
-  const unsigned step_bytes = (unsigned)BR * ld * 2;
-  char* const stage_base = smem + (isL ? 0 : TILE_BYTES) + (wave & 3) * PPW * 1024;
-
-  constexpr int PT = 8, QT = 4;   // 16x16 tiles per wave: 128 p x 64 q
-  f32x4 acc[PT][QT];
-#pragma unroll
-  for (int i = 0; i < PT; ++i)
-#pragma unroll
-    for (int j = 0; j < QT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // transposed read of a 16-column x 32-deep operand: lane = 16g + 4qq + pp supplies row 8g + 4hh + qq,
-  // columns 4pp..4pp+3 ; two reads (hh = 0, 1) make the 8-element fragment
-  const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-  const int fl = (qq << 2) | ((g & 1) << 1);
-  const int rowpart = (8 * g + qq) * 512 + (pp & 1) * 8;
-  int offL[PT], offR[QT];
-#pragma unroll
-  for (int i = 0; i < PT; ++i) offL[i] = rowpart + (((((wp * 128 + i * 16) >> 3) | (pp >> 1)) ^ fl) << 4);
-#pragma unroll
-  for (int j = 0; j < QT; ++j) offR[j] = TILE_BYTES + rowpart + (((((wq * 64 + j * 16) >> 3) | (pp >> 1)) ^ fl) << 4);
-  auto frag = [&](const char* ptr) {
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ptr));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ptr + 4 * 512));
-    return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) buf_glds16(rsrc, stage_base + i * 1024, voff[i], s_lo * step_bytes);
-  for (int s = s_lo; s < s_hi; ++s) {
-    const int cur = (s - s_lo) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const char* buf = smem + cur * BUF_BYTES;
-    char* nbase = stage_base + (cur ^ 1) * BUF_BYTES;
-    const bool more = s + 1 < s_hi;
-    const int soff = (s + 1) * step_bytes;
-    // four groups of 16 MFMAs (4 p-tiles x 4 q-tiles x one 32-deep k-step): a group lasts ~256 MFMA cycles, long enough to
-    // cover the latency of the next group's eight transposed reads (the 8-MFMA grouping of the NT kernel stalled here)
-    bf16x8 rq[2][QT], lq[2][4];
-    u32x4 stg[PPW];       // next stage through VGPRs + ds_write (as the 32x32x16 kernel)
-#pragma unroll
-    for (int j = 0; j < QT; ++j) rq[0][j] = frag(buf + offR[j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lq[0][i] = frag(buf + offL[i]);
-#pragma unroll
-    for (int gidx = 0; gidx < 4; ++gidx) {
-      const int ks = gidx >> 1, half = gidx & 1;
-      if (more) {
-        stg[2 * gidx] = buf_load16(rsrc, voff[2 * gidx], soff);
-        stg[2 * gidx + 1] = buf_load16(rsrc, voff[2 * gidx + 1], soff);
-      }
-      if (gidx < 3) {
-        const int ks2 = (gidx + 1) >> 1, half2 = (gidx + 1) & 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lq[(gidx + 1) & 1][i] = frag(buf + offL[4 * half2 + i] + ks2 * 32 * 512);
-      }
-      if (gidx == 0) {
-#pragma unroll
-        for (int j = 0; j < QT; ++j) rq[1][j] = frag(buf + offR[j] + 32 * 512);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < QT; ++j)
-          acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rq[ks][j], lq[gidx & 1][i], acc[4 * half + i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < PPW; ++i) *(u32x4*)(nbase + i * 1024 + lane * 16) = stg[i];
-    }
-  }
-
-  // D[i = q][j = p]: lane owns row p = 16*pt + (lane&15), columns q = 16*qt + 4*(lane>>4) + 0..3
-  const int pl0 = wp * 128 + (lane & 15), ql0 = wq * 64 + 4 * (lane >> 4);
-  if constexpr (WS) {
-    float* wt = a.ws + ((size_t)split * ntile + tile) * (BP * BQ);
-#pragma unroll
-    for (int i = 0; i < PT; ++i)
-#pragma unroll
-      for (int j = 0; j < QT; ++j) *(f32x4*)(wt + (pl0 + 16 * i) * BQ + ql0 + 16 * j) = acc[i][j];
-  } else {
-#pragma unroll
-    for (int i = 0; i < PT; ++i)
-#pragma unroll
-      for (int j = 0; j < QT; ++j) {
-        const int pg = p0 + pl0 + 16 * i, qg = q0 + ql0 + 16 * j;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (pg < a.P && qg + r < a.Q) atomicAdd(a.out + (size_t)pg * a.ldo + qg + r, acc[i][j][r]);
-      }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -478,6 +191,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_pp_kernel(const GemmTnArgs a,
   }
 }
 
+#ifdef VITAMD_EXPERIMENTAL
+#include "experimental/gemm_tn_variants.inc"
+#endif
+
 // out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; one float4 per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int Q, int ldo,
                                                             int tiles_q, int ntile, int splits, int accumulate) {
@@ -512,7 +229,9 @@ static int auto_splits(int R, int P, int Q, int requested) {
 
 extern "C" long vitamd_gemm_tn_ws_bytes(int R, int P, int Q, int splits) {
   if (R <= 0 || P <= 0 || Q <= 0) return 0;
+#ifdef VITAMD_EXPERIMENTAL
   if (vitamd_gemm_tn_wide_ok(R, P, Q, splits)) return (long)vitamd_gemm_tn_wide_splits(R, P, Q) * P * Q * (long)sizeof(float);
+#endif
   const long ntile = (long)((P + BP - 1) / BP) * ((Q + BQ - 1) / BQ);
   return (long)auto_splits(R, P, Q, splits) * ntile * BP * BQ * (long)sizeof(float);
 }
@@ -521,54 +240,42 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   if (a.R <= 0 || a.P <= 0 || a.Q <= 0 || a.ldl % 8 || a.ldr % 8 || a.ldl < a.P || a.ldr < a.Q || a.ldo < a.Q) return VITAMD_ERR_SHAPE;
   if ((size_t)(a.R + BR) * a.ldl * 2 >= 0x80000000ull || (size_t)(a.R + BR) * a.ldr * 2 >= 0x80000000ull) return VITAMD_ERR_SHAPE;
   if (!a.L || !a.Rm || !a.out) return VITAMD_ERR_ARG;
+#ifdef VITAMD_EXPERIMENTAL
   if (a.ws && a.ldl == a.P && a.ldr == a.Q && vitamd_gemm_tn_wide_ok(a.R, a.P, a.Q, a.splits) &&
       a.ws_bytes >= (size_t)vitamd_gemm_tn_wide_splits(a.R, a.P, a.Q) * a.P * a.Q * sizeof(float))
     return vitamd_gemm_tn_wide_launch(a, stream);
+#endif
   const int tiles_p = (a.P + BP - 1) / BP, tiles_q = (a.Q + BQ - 1) / BQ;
   const int ntile = tiles_p * tiles_q;
-  const int nsteps = (a.R + BR - 1) / BR;
   const int splits = auto_splits(a.R, a.P, a.Q, a.splits);
-  static bool attr_done = false;
-  constexpr int lds = 2 * BUF_BYTES;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_tn16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_tn16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return VITAMD_ERR_LAUNCH;
-    attr_done = true;
-  }
+  constexpr int lds = 8 * QSLOT;                                  // the ring of eight quarter slots (= two 64-row stages)
   const bool use_ws = a.ws != nullptr && a.ws_bytes >= (size_t)splits * ntile * BP * BQ * sizeof(float);
   if (!use_ws && !a.accumulate) return VITAMD_ERR_ARG;      // overwrite mode needs the workspace: the atomic form can only add to `out`
-  const bool k16 = (g_vitamd_debug & 64) != 0;   // A/B knob: bit 6 selects the 16x16x32 variant (whole-step A/B: equal to the 32x32x16 form since its regrouping)
+  const dim3 grid(ntile * splits), block(NW * 64);
+#ifdef VITAMD_EXPERIMENTAL
+  {   // A/B knobs: bit 6 = 16x16x32 round-1 form; bits 26-28: 1-3 timing-only ablations, 5 = round-1 LDS-DMA, 6 = round-1 VGPR-staged, 7 = ping-pong D = 6
+    const int sel = (g_vitamd_debug >> 26) & 7;
+    if (use_ws && ((g_vitamd_debug & 64) || sel)) {
+      if (g_vitamd_debug & 64) { if (int e = set_lds(gemm_tn16_kernel<true>, lds)) return e; hipLaunchKernelGGL(gemm_tn16_kernel<true>, grid, block, lds, stream, a, tiles_p, tiles_q, splits); }
+      else {
+        auto kern = sel == 1 ? gemm_tn_kernel<true, 1> : sel == 2 ? gemm_tn_kernel<true, 2> : sel == 3 ? gemm_tn_kernel<true, 3>
+                  : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_kernel<true, 4> : gemm_tn_pp_kernel<true, 8, 6>;
+        if (int e = set_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, a, tiles_p, tiles_q, splits);
+      }
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits, a.accumulate);
+      return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+    }
+  }
+#endif
   if (use_ws) {
-    if (k16) hipLaunchKernelGGL(gemm_tn16_kernel<true>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
-    else {
-      // staging path: global -> VGPR -> ds_write (default: whole-step A/B -0.6..-0.8 ms against LDS-DMA for THIS kernel, while
-      // the NT kernel is 1.1 ms slower with it; tools/ab_dbg.py).  dbg bits 26-28: 5 = LDS-DMA form, 1-3 = timing-only ablations
-      const int sel = (g_vitamd_debug >> 26) & 7;
-      auto kern = sel == 1 ? gemm_tn_kernel<true, 1> : sel == 2 ? gemm_tn_kernel<true, 2> : sel == 3 ? gemm_tn_kernel<true, 3>
-                : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_kernel<true, 4> : sel == 7 ? gemm_tn_pp_kernel<true, 8, 6>
-                : gemm_tn_pp_kernel<true, 8, 4>;      // default: the ping-pong kernel; 6 = the round-1 VGPR-staged kernel
-      static bool attr_sel[8] = {};
-      if (!attr_sel[sel]) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return VITAMD_ERR_LAUNCH;
-        attr_sel[sel] = true;
-      }
-      hipLaunchKernelGGL(kern, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
-    }
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q,
-                       ntile, splits, a.accumulate);
+    if (int e = set_lds(gemm_tn_pp_kernel<true, 8, 4>, lds)) return e;
+    hipLaunchKernelGGL((gemm_tn_pp_kernel<true, 8, 4>), grid, block, lds, stream, a, tiles_p, tiles_q, splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits,
+                       a.accumulate);
   } else {
-    if (k16) hipLaunchKernelGGL(gemm_tn16_kernel<false>, dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
-    else {
-      static bool attr_pp = false;
-      if (!attr_pp) {
-        if (hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<false, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return VITAMD_ERR_LAUNCH;
-        attr_pp = true;
-      }
-      hipLaunchKernelGGL((gemm_tn_pp_kernel<false, 8, 4>), dim3(ntile * splits), dim3(NW * 64), lds, stream, a, tiles_p, tiles_q, splits);
-    }
+    if (int e = set_lds(gemm_tn_pp_kernel<false, 8, 4>, lds)) return e;
+    hipLaunchKernelGGL((gemm_tn_pp_kernel<false, 8, 4>), grid, block, lds, stream, a, tiles_p, tiles_q, splits);
   }
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }

@@ -45,10 +45,9 @@ struct GemmTnArgs {
   int accumulate;  // with a workspace: 1 = out += sum, 0 = out = sum (no pre-zeroing needed)
 };
 
-extern int g_vitamd_debug;
 int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream);
 int vitamd_gemm_tn_impl(const GemmTnArgs& p, hipStream_t stream);
-// 256x384-tile weight-gradient kernel (gemm_tn_wide.hip)
+// experimental builds only: 256x384-tile weight-gradient kernel (experimental/gemm_tn_wide.hip)
 bool vitamd_gemm_tn_wide_ok(int R, int P, int Q, int requested_splits);
 int vitamd_gemm_tn_wide_splits(int R, int P, int Q);
 int vitamd_gemm_tn_wide_launch(const GemmTnArgs& a, hipStream_t stream);

@@ -58,14 +58,29 @@ class VitamdError(RuntimeError):
     pass
 
 
-def build(verbose: bool = False) -> str:
-    """Compile libvitamd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
-    if verbose or r.returncode != 0:
-        print(r.stdout[-4000:], r.stderr[-4000:])
-    if r.returncode != 0:
-        raise VitamdError("building libvitamd.so failed")
+EXP_LIB_PATH = os.path.join(_HERE, "libvitamd_exp.so")
+
+
+def build(verbose: bool = False, experimental: bool = True) -> str:
+    """Compile libvitamd.so for gfx950 with hipcc (cross-compiles without a GPU) and, unless told otherwise, libvitamd_exp.so: the
+    same sources with -DVITAMD_EXPERIMENTAL (measured alternative kernels + vitamd_set_debug) for the A/B tools under tools/.
+    The product and the tests of the product load libvitamd.so only."""
+    for args in ([], ["EXPERIMENTAL=1"])[: 2 if experimental else 1]:
+        r = subprocess.run(["make", "-C", CSRC, "-j8", *args], capture_output=True, text=True)
+        if verbose or r.returncode != 0:
+            print(r.stdout[-4000:], r.stderr[-4000:])
+        if r.returncode != 0:
+            raise VitamdError("building libvitamd%s.so failed" % ("_exp" if args else ""))
     return LIB_PATH
+
+
+def use_experimental():
+    """A/B tools only: make load() return libvitamd_exp.so (alternative kernels behind extra `tile` codes, vitamd_set_debug).
+    Must be called before the first load()."""
+    global LIB_PATH
+    if _lib is not None:
+        raise VitamdError("use_experimental() must come before the first load()")
+    LIB_PATH = EXP_LIB_PATH
 
 
 def load():
@@ -77,6 +92,9 @@ def load():
         raise VitamdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the HIP kernels are the only implementation of this path; there is no fallback)")
     lib = ctypes.CDLL(LIB_PATH)
+    if LIB_PATH == EXP_LIB_PATH:
+        lib.vitamd_set_debug.argtypes = [ctypes.c_int]
+        lib.vitamd_set_debug.restype = ctypes.c_int
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
