@@ -125,6 +125,11 @@ int vitamd_attention_bwd(const void* qkv, const void* o, const float* lse2, cons
 int vitamd_cast_f32_bf16(const float* in, void* out_bf16, long n, void* stream);
 /* bf16(x) * dropout mask (p, seed; element index) — the top layer's fc2 output gradient under dropout. */
 int vitamd_cast_f32_bf16_dropout(const float* in, void* out_bf16, long n, float dropout_p, unsigned long long seed, void* stream);
+/* out[i] = in[i] * keep(seed, i / group): nn.Dropout (group = 1; reference blocks.py:118 proj_drop, :168-170 Mlp.drop) and DropPath
+ * (group = elements per sample; blocks.py:124-152) in training mode.  keep = 1/(1-p) or 0 from the stateless (seed, index) hash;
+ * the backward is the same call on the gradient.  In place (out == in) is allowed. */
+int vitamd_dropout_bf16(const void* in, void* out, long n, long group, float dropout_p, unsigned long long seed, void* stream);
+int vitamd_dropout_f32(const float* in, float* out, long n, long group, float dropout_p, unsigned long long seed, void* stream);
 /* W fp32 [N,K] -> bf16 [N,K] (wb, may be NULL) and transposed bf16 [K,N] (wbt, may be NULL). */
 int vitamd_cast_transpose_weight(const float* w, void* wb, void* wbt, int N, int K, void* stream);
 /* The same for n weights in ONE launch.  desc_dev: device array of n records

@@ -109,3 +109,103 @@ def test_module_dropout_semantics(hip):
     for a, b in zip(g1, [p.grad for p in mp.parameters()]):
         assert torch.isfinite(b).all() and O.rel_l2(b.cpu(), 3.0 * a.cpu()) < 2e-2
     assert O.rel_l2(xg.grad.cpu(), 3.0 * gx1.cpu()) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 2: training-mode drop rates on the blocks.py surface (reference blocks.py:118 proj_drop, :168-170 Mlp.drop, :124-152 DropPath)
+def _mask(shape, p, seed, group=1):
+    """the kernel's keep-scale tensor (1/(1-p) or 0) for a seed, read off a tensor of ones"""
+    from vitamd import ops
+    return ops.dropout(torch.ones(shape, device="cuda"), p, seed, group=group).cpu()
+
+
+def test_dropout_kernel_masks(hip):
+    from vitamd import ops
+    x = torch.randn(64, 50, 128, device="cuda")
+    y = ops.dropout(x, 0.3, 1234)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    nz = y != 0
+    assert torch.allclose(y[nz], x[nz] / 0.7, rtol=1e-6)
+    assert torch.equal(ops.dropout(x, 0.3, 1234), y) and not torch.equal(ops.dropout(x, 0.3, 1235), y)     # stateless: (seed, index) decides
+    yb = ops.dropout(x.to(torch.bfloat16), 0.3, 1234)
+    assert torch.equal((yb != 0), (y != 0))
+    z = ops.dropout(x, 0.5, 99, group=50 * 128)                 # DropPath: one decision per sample
+    per_sample = (z != 0).float().mean(dim=(1, 2))
+    assert set(per_sample.tolist()) <= {0.0, 1.0} and 0 < per_sample.sum().item() < 64
+    kept = per_sample.bool()
+    assert torch.allclose(z[kept], 2.0 * x[kept], rtol=1e-6)
+    assert torch.equal(ops.dropout(x, 0.0, 5), x)
+
+
+def test_blocks_mlp_training_dropout_matches_masked_reference(hip):
+    """blocks.Mlp in training mode with drop > 0 and a DropPath around it: forward and every gradient against an fp32 torch
+    computation that uses the SAME three masks (re-generated from the seeds the module draws from torch's generator)."""
+    import blocks as BK
+    from vitamd.functions import new_seed
+    torch.manual_seed(0)
+    m = BK.Mlp(128, 256, drop=0.25).cuda().train()
+    x = torch.randn(6, 9, 128, device="cuda", requires_grad=True)
+    dy = torch.randn(6, 9, 128, device="cuda")
+    p, pp = 0.25, 0.5
+    torch.manual_seed(77)
+    s_in, s_out, s_path = new_seed(), new_seed(), new_seed()
+    torch.manual_seed(77)
+    y = m(x, _drop_path=pp)
+    (y * dy).sum().backward()
+    k_in, k_out = _mask((54, 256), p, s_in).cuda(), _mask((54, 128), p, s_out).cuda()
+    k_path = _mask((6, 9 * 128), pp, s_path, group=9 * 128).view(6, 9, 128).cuda()
+    xr = x.detach().clone().requires_grad_(True)
+    w1, b1, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias))
+    h = torch.nn.functional.gelu(xr.view(54, 128) @ w1.t() + b1) * k_in
+    yr = ((h @ w2.t() + b2) * k_out).view(6, 9, 128) * k_path
+    (yr * dy).sum().backward()
+    assert O.rel_l2(y.detach().cpu(), yr.detach().cpu()) < 1e-2
+    assert O.rel_l2(x.grad.cpu(), xr.grad.cpu()) < 2e-2
+    for got, want in ((m.fc1.weight.grad, w1.grad), (m.fc1.bias.grad, b1.grad), (m.fc2.weight.grad, w2.grad), (m.fc2.bias.grad, b2.grad)):
+        assert O.rel_l2(got.cpu(), want.cpu()) < 2e-2
+    m.eval()
+    assert torch.equal(m(x.detach()), m(x.detach()))                                   # eval: deterministic, no mask
+
+
+def test_blocks_attention_and_uvit_training_drops(hip):
+    import blocks as BK
+    from vitamd.functions import new_seed
+    torch.manual_seed(1)
+    att = BK.Attention(128, 2, qkv_bias=True, proj_drop=0.2).cuda()
+    x = torch.randn(8, 21, 128, device="cuda")
+    att.eval()
+    y0 = att(x)
+    att.train()
+    torch.manual_seed(5)
+    s_proj, s_path = new_seed(), new_seed()
+    torch.manual_seed(5)
+    y1 = att(x, _drop_path=0.5)
+    k = _mask((8 * 21, 128), 0.2, s_proj).view(8, 21, 128).cuda() * _mask((8, 21 * 128), 0.5, s_path, group=21 * 128).view(8, 21, 128).cuda()
+    assert O.rel_l2(y1.cpu(), (y0 * k).cpu()) < 1e-2                     # = the eval output under the two masks (bf16 rounding of the scaled values)
+    # whole block: training with every rate on runs, differs from eval, gives finite gradients, and checkpointing reproduces it bit for bit
+    blk = BK.UViTBlock(128, 2, qkv_bias=True, drop=0.1, drop_path=0.2).cuda().train()
+    xb = torch.randn(8, 21, 128, device="cuda", requires_grad=True)
+    torch.manual_seed(9)
+    yb = blk(xb)
+    yb.sum().backward()
+    g_plain = {k_: p.grad.clone() for k_, p in blk.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in g_plain.values()) and torch.isfinite(xb.grad).all()
+    blk.eval()
+    assert O.rel_l2(yb.detach().cpu(), blk(xb.detach()).cpu()) > 1e-2
+    blk.train()
+    blk.use_checkpoint = True
+    blk.zero_grad(set_to_none=True)
+    torch.manual_seed(9)
+    yc = blk(xb)
+    yc.sum().backward()
+    assert torch.equal(yc, yb)
+    for k_, p in blk.named_parameters():
+        assert O.rel_l2(p.grad.cpu(), g_plain[k_].cpu()) < 1e-5, k_          # (LayerNorm gamma / beta gradients are atomic sums: order differs)
+    # DropPath module alone
+    dp = BK.DropPath(0.5).cuda().train()
+    z = dp(x)
+    frac = (z.flatten(1).abs().sum(1) != 0).float().mean().item()
+    assert 0.0 < frac < 1.0
+    dp.eval()
+    assert torch.equal(dp(x), x)

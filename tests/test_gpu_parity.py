@@ -431,7 +431,8 @@ def test_vq_nearest_wide_codes(hip):
 
 def test_blocks_drop_rates_are_identity_in_eval(hip):
     """Reference semantics: nn.Dropout / DropPath do nothing in eval mode (blocks.py:124-139).  A block built WITH drop rates
-    must reproduce the reference's (drop-free) golden output in eval mode, and refuse to train."""
+    must reproduce the reference's (drop-free) golden output in eval mode; training with the rates on is covered by
+    tests/test_gpu_dropout.py (masks, masked-reference parity, checkpointing)."""
     import blocks as BK
     case = load_golden("blocks_tiny.pt")["uvit_bias"]
     m = BK.UViTBlock(dim=128, num_heads=2, qkv_bias=True, drop=0.1, attn_drop=0.1, drop_path=0.2)
@@ -442,8 +443,7 @@ def test_blocks_drop_rates_are_identity_in_eval(hip):
         y = m(x)
     assert O.rel_l2(y.cpu(), case["y"]) < 2 * case["ref_bf16_floor"]["y"] + 2e-3
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(x)
+    assert torch.isfinite(m(x)).all()
 
 
 def test_graphed_step_matches_eager(hip):

@@ -128,7 +128,8 @@ def test_blocks_surface_state_dict_contract():
     assert isinstance(BK.ATTENTION_MODE, str)
     blk = BK.UViTBlock(128, 2, drop=0.1, drop_path=0.1)        # rates accepted (configs carry them) ...
     assert isinstance(blk.drop_path, BK.DropPath) and blk.mlp.drop.p == 0.1
-    with pytest.raises(NotImplementedError):                    # ... training with them is refused, loudly, before any kernel runs
+    from vitamd.lib import VitamdError
+    with pytest.raises(VitamdError):                            # ... and training with them runs on the kernels: a host tensor is refused
         blk(torch.zeros(1, 4, 128))
     with pytest.raises(NotImplementedError):
         BK.Attention(96, 2)            # head_dim 48

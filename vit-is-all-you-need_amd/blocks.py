@@ -27,7 +27,7 @@ import torch.nn as nn
 from einops.layers.torch import Rearrange
 
 from vitamd import ops
-from vitamd.block_functions import AttnProjFn, BlockFn, Conv3x3Fn, LayerNormAffineFn, MlpFn
+from vitamd.block_functions import AttnProjFn, BlockFn, Conv3x3Fn, DropPathFn, LayerNormAffineFn, MlpFn
 from vitamd.functions import PatchEmbedFn, linear
 
 ATTENTION_MODE = "hip"   # the reference picks 'flash' / 'xformers' / 'math' at import (blocks.py:72-81)
@@ -37,16 +37,6 @@ print(f"attention mode is {ATTENTION_MODE}")
 def _need_gelu(act_layer):
     if act_layer is not nn.GELU:
         raise NotImplementedError("only the erf-GELU activation is fused into the GEMM epilogues")
-
-
-def _no_train_drop(mod, rates):
-    """Non-zero drop rates are accepted at construction (configs and checkpoints of the reference carry them) and are the
-    identity in eval mode, as in the reference; TRAINING with them is not built on this surface - fail loudly."""
-    if mod.training:
-        for what, rate in rates.items():
-            if rate:
-                raise NotImplementedError(f"training with {what} = {rate} is not implemented for the blocks.py surface "
-                                          "(transformer.py's dropout is: vitamd/functions.py)")
 
 
 def _heads(dim, num_heads):
@@ -112,15 +102,18 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, x):
-        _no_train_drop(self, {"proj_drop": self.proj_drop.p})     # attn_drop is unused by the reference's 'flash' mode as well
-        return AttnProjFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.num_heads)
+    def forward(self, x, _drop_path=0.0):
+        # attn_drop is unused by the reference's 'flash' mode as well; proj_drop is live in training (reference blocks.py:118)
+        return AttnProjFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.num_heads,
+                                float(self.proj_drop.p) if self.training else 0.0, float(_drop_path))
 
 
 def drop_path(x, drop_prob: float = 0., training: bool = False):
+    """Stochastic depth per sample (reference blocks.py:124-139): identity in eval mode or at rate 0; in training a whole sample's
+    branch is zeroed with probability drop_prob and the survivors are scaled by 1/(1 - drop_prob) - on the dropout kernel."""
     if drop_prob == 0. or not training:
         return x
-    raise NotImplementedError("training with drop_path > 0 is not implemented for the blocks.py surface")
+    return DropPathFn.apply(x, float(drop_prob))
 
 
 class DropPath(nn.Module):
@@ -145,9 +138,9 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x):
-        _no_train_drop(self, {"drop": self.drop.p})
-        return MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+    def forward(self, x, _drop_path=0.0):
+        return MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias,
+                           float(self.drop.p) if self.training else 0.0, float(_drop_path))
 
 
 class UViTBlock(nn.Module):
@@ -165,16 +158,26 @@ class UViTBlock(nn.Module):
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
         self.skip_linear = nn.Linear(2 * dim, dim) if skip else None
-        self.use_checkpoint = use_checkpoint       # accepted for signature parity; activations fit in HBM, nothing is recomputed
+        self.use_checkpoint = use_checkpoint
 
     def forward(self, x, skip=None):
+        if self.use_checkpoint and torch.is_grad_enabled():
+            # activation checkpointing (reference blocks.py:188-192): only the block input is kept, the forward is re-run in backward.
+            # The dropout seeds come from torch's CPU generator, whose state checkpoint() restores for the re-run: same masks.
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(self._forward, x, skip, use_reentrant=False)
         return self._forward(x, skip)
 
     def _forward(self, x, skip=None):
-        _no_train_drop(self, {"drop": self.mlp.drop.p, "proj_drop": self.attn.proj_drop.p,
-                              "drop_path": getattr(self.drop_path, "drop_prob", 0.) or 0.})
         if self.skip_linear is not None:
             x = linear(torch.cat([x, skip], dim=-1), self.skip_linear.weight, self.skip_linear.bias)
+        p_path = float(getattr(self.drop_path, "drop_prob", 0.) or 0.) if self.training else 0.0
+        if self.training and (p_path or self.mlp.drop.p or self.attn.proj_drop.p):
+            # training with drop rates (reference blocks.py:194-201): x + drop_path(attn(norm1(x))), then x + drop_path(mlp(norm2(x))),
+            # the branches on the drop-aware Functions (masks from the stateless hash, regenerated in backward); the two residual adds
+            # and the LayerNorms run un-fused here (fp32 stream)
+            x = x + self.attn(_ln(self.norm1, x), _drop_path=p_path)
+            return x + self.mlp(_ln(self.norm2, x), _drop_path=p_path)
         return BlockFn.apply(x, self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
                              self.attn.proj.weight, self.attn.proj.bias, self.norm2.weight, self.norm2.bias,
                              self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias,

@@ -3,7 +3,7 @@
 #include "vitamd_internal.h"
 #include "../../include/vitamd.h"
 
-extern "C" int vitamd_abi_version(void) { return 4; }
+extern "C" int vitamd_abi_version(void) { return 5; }
 
 #ifdef VITAMD_EXPERIMENTAL
 int g_vitamd_debug = 0;

@@ -23,6 +23,17 @@ __global__ __launch_bounds__(256) void cast_dropout_kernel(const float* __restri
     out[i] = f2bf(round_bf16(in[i]) * dropout_keep(i, slo, shi, thresh, scale));
 }
 
+// out[i] = in[i] * keep(seed, i / group): dropout with one mask decision per `group` consecutive elements.  group = 1 is nn.Dropout
+// (reference blocks.py:118,168-170: proj_drop, Mlp.drop); group = elements per sample is DropPath (blocks.py:124-139, one decision per
+// sample, scaled by 1/keep_prob).  The backward applies the same call to the gradient (same seed -> same mask).  In place is fine.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ in, T* __restrict__ out, size_t n, size_t group, unsigned thresh,
+                                                      float scale, unsigned slo, unsigned shi) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (T)((float)in[i] * dropout_keep(group == 1 ? i : i / group, slo, shi, thresh, scale));
+}
+
 // W fp32 [N,K] -> Wb bf16 [N,K] (optional) and WbT bf16 [K,N] (optional); 64x64 tiles through LDS
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, __bf16* __restrict__ wb,
                                                              __bf16* __restrict__ wbt, int N, int K) {
@@ -315,6 +326,24 @@ extern "C" int vitamd_cast_f32_bf16_dropout(const float* in, void* out_bf16, lon
   hipLaunchKernelGGL(cast_dropout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (__bf16*)out_bf16, (size_t)n, thresh,
                      1.0f / (1.0f - dropout_p), (unsigned)seed, (unsigned)(seed >> 32));
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+
+template <typename T>
+static int launch_dropout(const void* in, void* out, long n, long group, float dropout_p, unsigned long long seed, void* stream) {
+  if (n <= 0 || group <= 0) return n == 0 ? VITAMD_OK : VITAMD_ERR_SHAPE;
+  if (!in || !out || !(dropout_p >= 0.f) || dropout_p >= 1.f) return VITAMD_ERR_ARG;
+  unsigned thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  if (dropout_p > 0.f && thresh == 0u) thresh = 1u;
+  int grid = (int)(((size_t)n + 255) / 256); grid = grid > 8192 ? 8192 : grid;
+  hipLaunchKernelGGL(dropout_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, (size_t)n, (size_t)group, thresh,
+                     1.0f / (1.0f - dropout_p), (unsigned)seed, (unsigned)(seed >> 32));
+  return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+extern "C" int vitamd_dropout_bf16(const void* in, void* out, long n, long group, float dropout_p, unsigned long long seed, void* stream) {
+  return launch_dropout<__bf16>(in, out, n, group, dropout_p, seed, stream);
+}
+extern "C" int vitamd_dropout_f32(const float* in, float* out, long n, long group, float dropout_p, unsigned long long seed, void* stream) {
+  return launch_dropout<float>(in, out, n, group, dropout_p, seed, stream);
 }
 
 extern "C" int vitamd_cast_transpose_weight(const float* w, void* wb, void* wbt, int N, int K, void* stream) {

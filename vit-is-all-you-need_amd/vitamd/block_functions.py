@@ -94,12 +94,37 @@ class BlockFn(torch.autograd.Function):
                 dW1, db1, dW2, db2, None, None)
 
 
-class AttnProjFn(torch.autograd.Function):
-    """proj(attention(qkv(x)))  — reference blocks.Attention (blocks.py:84-121), dropout-free."""
+def _seeds(*rates):
+    """one fresh 64-bit seed per non-zero rate (0 otherwise); drawn from torch's CPU generator like functions.new_seed()"""
+    from .functions import new_seed
+    return tuple(new_seed() if r > 0 else 0 for r in rates)
+
+
+class DropPathFn(torch.autograd.Function):
+    """Stochastic depth on a stand-alone tensor (reference blocks.py:124-152): one keep decision per sample, scaled by 1/keep_prob."""
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, wqkv, bqkv, wo, bo, n_heads):
+    def forward(ctx, x, p):
+        xf = _f32c(x)
+        (seed,) = _seeds(p)
+        ctx.meta = (p, seed, xf[0].numel() if xf.dim() > 0 else 1, x.dtype)
+        return ops.dropout(xf, p, seed, group=ctx.meta[2]).to(x.dtype)
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        p, seed, group, xdtype = ctx.meta
+        return ops.dropout(_f32c(g), p, seed, group=group).to(xdtype), None
+
+
+class AttnProjFn(torch.autograd.Function):
+    """drop_path(proj_drop(proj(attention(qkv(x)))))  — reference blocks.Attention (blocks.py:84-121) and the DropPath a UViTBlock wraps
+    around it (blocks.py:194-199).  p_proj / p_path = 0 (eval mode) is the identity on those two."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, wqkv, bqkv, wo, bo, n_heads, p_proj=0.0, p_path=0.0):
         B, N, D = x.shape
         xb = ops.cast_bf16(_f32c(x).view(B * N, D))
         wqkv_b, _ = WEIGHTS.get(wqkv, True)
@@ -107,6 +132,11 @@ class AttnProjFn(torch.autograd.Function):
         qkv = ops.gemm_nt(xb, wqkv_b, ops.EPI_BIAS_BF16, bias=_f32c(bqkv) if bqkv is not None else None)
         o, lse = ops.attention_fwd(qkv, B, N, n_heads, False)
         y = ops.gemm_nt(o, wo_b, ops.EPI_BIAS_BF16, bias=_f32c(bo))
+        ctx.drops = (p_proj, p_path) + _seeds(p_proj, p_path)
+        if p_proj > 0:
+            ops.dropout(y, p_proj, ctx.drops[2], inplace=True)
+        if p_path > 0:
+            ops.dropout(y, p_path, ctx.drops[3], group=N * D, inplace=True)
         ctx.save_for_backward(xb, qkv, o, lse)
         ctx.params = (wqkv, bqkv, wo)
         ctx.meta = (B, N, D, n_heads, x.dtype)
@@ -120,6 +150,11 @@ class AttnProjFn(torch.autograd.Function):
         xb, qkv, o, lse = ctx.saved_tensors
         dev = g.device
         dy = ops.cast_bf16(_f32c(g).view(B * N, D))
+        p_proj, p_path, s_proj, s_path = ctx.drops
+        if p_path > 0:
+            ops.dropout(dy, p_path, s_path, group=N * D, inplace=True)
+        if p_proj > 0:
+            ops.dropout(dy, p_proj, s_proj, inplace=True)
         dbo = ops.colsum(dy)
         _, wo_t = WEIGHTS.get(wo, True)
         _, wqkv_t = WEIGHTS.get(wqkv, True)
@@ -131,21 +166,32 @@ class AttnProjFn(torch.autograd.Function):
         dWqkv = torch.empty((3 * D, D), dtype=F32, device=dev)
         ops.gemm_tn(dqkv, xb, dWqkv, accumulate=False)
         dx = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)
-        return dx.view(B, N, D).to(xdtype), dWqkv, dbqkv if bqkv is not None else None, dWo, dbo, None
+        return dx.view(B, N, D).to(xdtype), dWqkv, dbqkv if bqkv is not None else None, dWo, dbo, None, None, None
 
 
 class MlpFn(torch.autograd.Function):
-    """fc2(gelu(fc1(x)))  — reference blocks.Mlp (blocks.py:155-171), dropout-free."""
+    """drop_path(drop(fc2(drop(gelu(fc1(x))))))  — reference blocks.Mlp (blocks.py:155-171: the same nn.Dropout after the activation and
+    after fc2, two independent masks) and the DropPath a UViTBlock wraps around it.  p_drop / p_path = 0 is the identity on those."""
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, p_drop=0.0, p_path=0.0):
         lead, K = x.shape[:-1], x.shape[-1]
         xb = ops.cast_bf16(_f32c(x).reshape(-1, K))
         w1_b, _ = WEIGHTS.get(w1, True)
         w2_b, _ = WEIGHTS.get(w2, True)
         pre, h = ops.gemm_nt(xb, w1_b, ops.EPI_GELU_DG, bias=_f32c(b1))
+        ctx.drops = (p_drop, p_path) + _seeds(p_drop, p_drop, p_path)
+        if p_drop > 0:
+            # the mask of the first dropout goes onto BOTH gelu(pre) and the stored gelu'(pre): the backward's fused multiply by
+            # the stored derivative then carries it, and the fc1 bias gradient (column sums of that product) comes out right
+            ops.dropout(h, p_drop, ctx.drops[2], inplace=True)
+            ops.dropout(pre, p_drop, ctx.drops[2], inplace=True)
         y = ops.gemm_nt(h, w2_b, ops.EPI_BIAS_BF16, bias=_f32c(b2))
+        if p_drop > 0:
+            ops.dropout(y, p_drop, ctx.drops[3], inplace=True)
+        if p_path > 0:
+            ops.dropout(y, p_path, ctx.drops[4], group=y.numel() // lead[0] if len(lead) > 1 else y.shape[1], inplace=True)
         ctx.save_for_backward(xb, pre, h)
         ctx.params = (w1, w2)
         ctx.meta = (lead, K, x.dtype)
@@ -160,6 +206,11 @@ class MlpFn(torch.autograd.Function):
         dev = g.device
         Dh, Dout = h.shape[1], w2.shape[0]
         dy = ops.cast_bf16(_f32c(g).reshape(-1, Dout))
+        p_drop, p_path, _, s_out, s_path = ctx.drops
+        if p_path > 0:
+            ops.dropout(dy, p_path, s_path, group=dy.numel() // lead[0] if len(lead) > 1 else dy.shape[1], inplace=True)
+        if p_drop > 0:
+            ops.dropout(dy, p_drop, s_out, inplace=True)
         db2 = ops.colsum(dy)
         _, w1_t = WEIGHTS.get(w1, True)
         _, w2_t = WEIGHTS.get(w2, True)
@@ -170,7 +221,7 @@ class MlpFn(torch.autograd.Function):
         dW1 = torch.empty((Dh, K), dtype=F32, device=dev)
         ops.gemm_tn(dpre, xb, dW1, accumulate=False)
         dx = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)
-        return dx.view(*lead, K).to(xdtype), dW1, db1, dW2, db2
+        return dx.view(*lead, K).to(xdtype), dW1, db1, dW2, db2, None, None
 
 
 class LayerNormAffineFn(torch.autograd.Function):

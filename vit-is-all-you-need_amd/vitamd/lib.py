@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitamd.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c = ctypes
 _P, _I, _F, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_ulonglong
@@ -38,6 +38,8 @@ SIGNATURES = {
     "vitamd_linear_dropout_resid_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P],
     "vitamd_cast_f32_bf16_dropout": [_P, _P, _L, _F, _U64, _P],
     "vitamd_cast_f32_bf16": [_P, _P, _L, _P],
+    "vitamd_dropout_bf16": [_P, _P, _L, _L, _F, _U64, _P],
+    "vitamd_dropout_f32": [_P, _P, _L, _L, _F, _U64, _P],
     "vitamd_cast_transpose_weight": [_P, _P, _P, _I, _I, _P],
     "vitamd_cast_transpose_batched": [_P, _I, _I, _P],
     "vitamd_im2col_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],

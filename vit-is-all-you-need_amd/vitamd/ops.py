@@ -242,6 +242,17 @@ def cast_bf16_dropout(x, dropout):
     return out
 
 
+def dropout(x, p, seed, group=1, inplace=False):
+    """x (bf16 or fp32) * keep(seed, index // group): training-mode nn.Dropout (group 1) / DropPath (group = elements per sample)."""
+    if x.dtype not in (BF16, F32):
+        raise _lib.VitamdError(f"dropout: expected bf16 or fp32, got {x.dtype}")
+    _need(x, x.dtype, "x")
+    out = x if inplace else torch.empty_like(x)
+    fn = _L().vitamd_dropout_bf16 if x.dtype == BF16 else _L().vitamd_dropout_f32
+    _lib.check(fn(_p(x), _p(out), x.numel(), int(group), float(p), int(seed), _stream()), "dropout")
+    return out
+
+
 def cast_bf16(x):
     _need(x, F32, "x")
     out = torch.empty(x.shape, dtype=BF16, device=x.device)
