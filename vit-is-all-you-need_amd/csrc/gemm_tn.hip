@@ -253,13 +253,13 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   if (!use_ws && !a.accumulate) return VITAMD_ERR_ARG;      // overwrite mode needs the workspace: the atomic form can only add to `out`
   const dim3 grid(ntile * splits), block(NW * 64);
 #ifdef VITAMD_EXPERIMENTAL
-  {   // A/B knobs: bit 6 = 16x16x32 round-1 form; bits 26-28: 1-3 timing-only ablations, 5 = round-1 LDS-DMA, 6 = round-1 VGPR-staged, 7 = ping-pong D = 6
+  {   // A/B knobs: bit 6 = 16x16x32 round-1 form; bits 26-28: 1-3 timing-only ablations, 4 = ping-pong on 16x16x32, 5 = round-1 LDS-DMA, 6 = round-1 VGPR-staged, 7 = ping-pong D = 6
     const int sel = (g_vitamd_debug >> 26) & 7;
     if (use_ws && ((g_vitamd_debug & 64) || sel)) {
       if (g_vitamd_debug & 64) { if (int e = set_lds(gemm_tn16_kernel<true>, lds)) return e; hipLaunchKernelGGL(gemm_tn16_kernel<true>, grid, block, lds, stream, a, tiles_p, tiles_q, splits); }
       else {
         auto kern = sel == 1 ? gemm_tn_kernel<true, 1> : sel == 2 ? gemm_tn_kernel<true, 2> : sel == 3 ? gemm_tn_kernel<true, 3>
-                  : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_kernel<true, 4> : gemm_tn_pp_kernel<true, 8, 6>;
+                  : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_kernel<true, 4> : sel == 4 ? gemm_tn_pp16_kernel<true> : gemm_tn_pp_kernel<true, 8, 6>;
         if (int e = set_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a, tiles_p, tiles_q, splits);
       }

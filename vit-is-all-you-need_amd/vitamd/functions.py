@@ -513,6 +513,32 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+_PADDED = {}     # id(weight) -> zero-padded bf16 copies (and padded fp32 bias) of a generic Linear's parameters
+
+
+def _padded_weight(w, b, Np, Kp):
+    """bf16 [Np,Kp] / transposed [Kp,Np] copies of w zero-padded to multiples of 64, and the padded fp32 bias; re-made only when the
+    parameter (or the bias) changed or the weight-cache epoch moved on (once per optimiser step), not on every call"""
+    base = w._base if w._base is not None else w          # callers hand in fresh views of a parameter (conv weights as [out, in*k*k]): key on the parameter
+    ent = _PADDED.get(id(base))
+    bver = -1 if b is None else b._version
+    if (ent is None or ent["ref"]() is not base or ent["ver"] != w._version or ent["ptr"] != w.data_ptr() or ent["epoch"] != WEIGHTS.epoch
+            or ent["bver"] != bver or ent["shape"] != (Np, Kp)):
+        if len(_PADDED) > 1024:
+            for k in [k for k, v in _PADDED.items() if v["ref"]() is None]:
+                del _PADDED[k]
+        Nout, K = w.shape
+        wp = torch.zeros((Np, Kp), dtype=F32, device=w.device)
+        wp[:Nout, :K] = w.detach()
+        bp = torch.zeros((Np,), dtype=F32, device=w.device)
+        if b is not None:
+            bp[:Nout] = b.detach()
+        wb, wbt = ops.cast_weight(wp, True, True)
+        ent = _PADDED[id(base)] = {"ref": weakref.ref(base), "ver": w._version, "ptr": w.data_ptr(), "epoch": WEIGHTS.epoch, "bver": bver,
+                                "shape": (Np, Kp), "wb": wb, "wbt": wbt, "bp": bp}
+    return ent["wb"], ent["wbt"], ent["bp"]
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b through the MFMA GEMMs for arbitrary (small, odd) feature sizes: the output dim
     is zero-padded to a multiple of 64 (it is the reduction dim of the input-gradient GEMM) and the
@@ -525,12 +551,7 @@ class LinearFn(torch.autograd.Function):
         Nout = w.shape[0]
         Np, Kp = _pad64(Nout), _pad64(K)
         dev = x.device
-        wp = torch.zeros((Np, Kp), dtype=F32, device=dev)
-        wp[:Nout, :K] = w.detach()
-        bp = torch.zeros((Np,), dtype=F32, device=dev)
-        if b is not None:
-            bp[:Nout] = b.detach()
-        wb, wbt = ops.cast_weight(wp, True, True)
+        wb, wbt, bp = _padded_weight(w, b, Np, Kp)
         xf = _f32c(x)
         if Kp != K:
             xpad = torch.zeros((M, Kp), dtype=F32, device=dev)
