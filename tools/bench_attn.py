@@ -18,10 +18,11 @@ def t(fn, n=10):
 cfgs = {"two_kernel": 0, "fused": 0x200}
 for a in sys.argv[1:]:
     k, v = a.split("="); cfgs[k] = int(v, 0)
-res = {k: [] for k in cfgs}; fw = []
+res = {k: [] for k in cfgs}; fw = []; fw_old = []
 ref = None
 for r in range(5):
-    fw.append(t(lambda: ops.attention_fwd(qkv, B, N, H)))
+    L.vitamd_set_debug(0x2000); fw.append(t(lambda: ops.attention_fwd(qkv, B, N, H))); L.vitamd_set_debug(0)
+    L.vitamd_set_debug(0); fw_old.append(t(lambda: ops.attention_fwd(qkv, B, N, H))); L.vitamd_set_debug(0)
     for k, bits in cfgs.items():
         L.vitamd_set_debug(bits)
         if r == 0:
@@ -30,5 +31,8 @@ for r in range(5):
             else: print(k, "rel diff vs first", float((dq.float() - ref).norm() / ref.norm()))
         res[k].append(t(lambda: ops.attention_bwd(qkv, o, lse, d_o, B, N, H)))
 L.vitamd_set_debug(0)
-print(f"fwd {statistics.median(fw):7.1f} us   (HBM floor 52 us)")
+o_old, lse_old = ops.attention_fwd(qkv, B, N, H)
+L.vitamd_set_debug(0x2000); o_new, lse_new = ops.attention_fwd(qkv, B, N, H); L.vitamd_set_debug(0); torch.cuda.synchronize()
+print("fwd persistent vs per-head: o equal", torch.equal(o_new, o_old), "lse equal", torch.equal(lse_new, lse_old))
+print(f"fwd persistent {statistics.median(fw):7.1f} us, per-head kernel {statistics.median(fw_old):7.1f} us   (HBM floor 52 us)")
 for k in cfgs: print(f"bwd {k:12s} {statistics.median(res[k]):7.1f} us  {['%.0f' % v for v in res[k]]}")

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 // The whole score row of a query fits in registers (NKT tiles x 16 fp32), so there is no online
 // rescaling: S for every key tile, one row maximum, exp2, then P.V.  Per element the VALU work is
 // fma + v_exp + add + cvt (the kernel is VALU-bound at dh = 64, not MFMA-bound).
-template <int NKT, bool DROP, bool RES = false>
+template <int NKT, bool DROP, bool CAUSAL, bool RES = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
     const int qrow = q0 + (lane & 31);
     bf16x8 qf[4];
     load_lane_frags(qbase, D3, N, q0, lane, qf);
-    const int t_end = a.causal ? qb + 1 : nt;
+    const int t_end = CAUSAL ? qb + 1 : nt;
     f32x16 s[NKT];
     float mx = NEG_BIG;
 #pragma unroll
@@ -311,11 +311,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
         for (int r = 0; r < 16; ++r) s[T][r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s[T], 0, 0, 0);
-        if (32 * T + 32 > N || (a.causal && T == qb)) {   // only boundary tiles need masking (wave-uniform)
+        if (32 * T + 32 > N || (CAUSAL && T == qb)) {   // only boundary tiles need masking (wave-uniform)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = 32 * T + acc_row(r, lane);
-            if (!(key < N && (!a.causal || key <= qrow))) s[T][r] = NEG_BIG;
+            if (!(key < N && (!CAUSAL || key <= qrow))) s[T][r] = NEG_BIG;
           }
         }
         mx = fmaxf(mx, max16(s[T]));
@@ -359,8 +359,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
   }
 }
 
+#ifdef VITAMD_EXPERIMENTAL
+#include "experimental/attention_fwd_persistent.inc"
+#endif
+
 // ------------------------------------------------------------------------------------------ backward, dQ
-template <bool DROP>
+template <bool DROP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    const int t_end = a.causal ? min(nt, qb + 1) : nt;
+    const int t_end = CAUSAL ? min(nt, qb + 1) : nt;
     for (int T = 0; T < t_end; ++T) {
       f32x16 s, dp;
 #pragma unroll
@@ -419,11 +423,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         if constexpr (DROP) dpr *= attn_keep(a, blockIdx.x, min(qrow, N - 1), min(32 * T + acc_row(r, lane), N - 1));
         s[r] = pexp * (dpr - delta);  // dS^T (the 1/sqrt(dh) factor is applied once at the end)
       }
-      if (32 * T + 32 > N || (a.causal && T == qb)) {   // boundary tiles: zero the masked keys
+      if (32 * T + 32 > N || (CAUSAL && T == qb)) {   // boundary tiles: zero the masked keys
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = 32 * T + acc_row(r, lane);
-          if (!(key < N && (!a.causal || key <= qrow))) s[r] = 0.f;
+          if (!(key < N && (!CAUSAL || key <= qrow))) s[r] = 0.f;
         }
       }
 #pragma unroll
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ backward, dK and dV
-template <bool DROP>
+template <bool DROP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    const int t_beg = a.causal ? kb : 0;  // queries before the key block never attend to it
+    const int t_beg = CAUSAL ? kb : 0;  // queries before the key block never attend to it
     for (int T = t_beg; T < nt; ++T) {
       f32x16 s, dp;
 #pragma unroll
@@ -502,11 +506,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
           pmat[r] = pexp * keep;
           s[r] = pexp * (dp[r] * keep - del4[i]);
         }
-        if (32 * T + 32 > N || k0 + 32 > N || (a.causal && T == kb)) {   // boundary tiles only (wave-uniform)
+        if (32 * T + 32 > N || k0 + 32 > N || (CAUSAL && T == kb)) {   // boundary tiles only (wave-uniform)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * u + i, query = qr + i;
-            if (!(query < N && krow < N && (!a.causal || krow <= query))) { pmat[r] = 0.f; s[r] = 0.f; }
+            if (!(query < N && krow < N && (!CAUSAL || krow <= query))) { pmat[r] = 0.f; s[r] = 0.f; }
           }
         }
       }
@@ -822,16 +826,20 @@ static bool attn_dropout(AttnArgs& a, float p, unsigned long long seed) {
   return true;
 }
 
-template <int K, bool DROP>
-static int launch_fwd_small(const AttnArgs& a, int lds, hipStream_t stream) {
+template <int K, bool DROP, bool CAUSAL>
+static int launch_fwd_small_c(const AttnArgs& a, int lds, hipStream_t stream) {
   if (a.resid_in) {
-    if (int e = set_lds((attn_fwd_small_kernel<K, DROP, true>), lds)) return e;
-    hipLaunchKernelGGL((attn_fwd_small_kernel<K, DROP, true>), dim3(a.B * a.H), dim3(256), lds, stream, a);
+    if (int e = set_lds((attn_fwd_small_kernel<K, DROP, CAUSAL, true>), lds)) return e;
+    hipLaunchKernelGGL((attn_fwd_small_kernel<K, DROP, CAUSAL, true>), dim3(a.B * a.H), dim3(256), lds, stream, a);
     return VITAMD_OK;
   }
-  if (int e = set_lds(attn_fwd_small_kernel<K, DROP>, lds)) return e;
-  hipLaunchKernelGGL((attn_fwd_small_kernel<K, DROP>), dim3(a.B * a.H), dim3(256), lds, stream, a);
+  if (int e = set_lds((attn_fwd_small_kernel<K, DROP, CAUSAL>), lds)) return e;
+  hipLaunchKernelGGL((attn_fwd_small_kernel<K, DROP, CAUSAL>), dim3(a.B * a.H), dim3(256), lds, stream, a);
   return VITAMD_OK;
+}
+template <int K, bool DROP>
+static int launch_fwd_small(const AttnArgs& a, int lds, hipStream_t stream) {      // causal / not: compile-time (fewer scalar registers: no runtime mask branches per tile)
+  return a.causal ? launch_fwd_small_c<K, DROP, true>(a, lds, stream) : launch_fwd_small_c<K, DROP, false>(a, lds, stream);
 }
 
 static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float* resid_in, float* resid_out, int B, int N, int H,
@@ -872,6 +880,17 @@ static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float
     }
     return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
   }
+#ifdef VITAMD_EXPERIMENTAL
+  if (nkt >= 4 && nkt <= 8 && !resid_in && !drop && (VITAMD_GDBG & 0x2000)) {     // persistent form (dbg bit 13 of experimental builds: the per-head kernel)
+    const int lds = 4 * npad * 128 + 8 * 4096;
+    const int grid = B * H < 256 ? B * H : 256;
+    int e = VITAMD_OK;
+#define FWD_PERS(K) case K: e = set_lds(attn_fwd_pers_kernel<K, false>, lds); if (!e) hipLaunchKernelGGL((attn_fwd_pers_kernel<K, false>), dim3(grid), dim3(512), lds, stream, a); break;
+    switch (nkt) { FWD_PERS(4) FWD_PERS(5) FWD_PERS(6) FWD_PERS(7) FWD_PERS(8) }
+#undef FWD_PERS
+    if (e) return e;
+  } else
+#endif
   if (nkt <= 8) {
     const int lds = 2 * npad * 128 + 4 * 4096;
     int e = VITAMD_OK;
@@ -933,16 +952,16 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
   }
 #endif
   const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
-  if (a.drop_thresh) {
-    if (int e = set_lds(attn_bwd_dq_kernel<true>, lds1)) return e;
-    if (int e = set_lds(attn_bwd_dkv_kernel<true>, lds2)) return e;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(B * H), dim3(256), lds1, stream, a);   // also writes delta
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(B * H), dim3(256), lds2, stream, a);
-  } else {
-    if (int e = set_lds(attn_bwd_dq_kernel<false>, lds1)) return e;
-    if (int e = set_lds(attn_bwd_dkv_kernel<false>, lds2)) return e;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(B * H), dim3(256), lds1, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(B * H), dim3(256), lds2, stream, a);
-  }
+  const dim3 grid(B * H), block(256);
+#define BWD_SMALL(DROP, CAUSAL)                                                                      \
+  do {                                                                                               \
+    if (int e = set_lds((attn_bwd_dq_kernel<DROP, CAUSAL>), lds1)) return e;                         \
+    if (int e = set_lds((attn_bwd_dkv_kernel<DROP, CAUSAL>), lds2)) return e;                        \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DROP, CAUSAL>), grid, block, lds1, stream, a); /* also writes delta */ \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DROP, CAUSAL>), grid, block, lds2, stream, a);          \
+  } while (0)
+  if (a.drop_thresh) { if (a.causal) BWD_SMALL(true, true); else BWD_SMALL(true, false); }
+  else { if (a.causal) BWD_SMALL(false, true); else BWD_SMALL(false, false); }
+#undef BWD_SMALL
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
