@@ -6,9 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops
 from vitamd import lib as _explib; _explib.use_experimental()
-cfgs = {"r1_pipe": 0, "pp256_4_6": 7, "pp320_4_6": 8, "pp320_6_6": 9}
-for a in sys.argv[1:]:
-    k, v = a.split("="); cfgs[k] = int(v, 0)
+cfgs = {"pp_auto": (0, 0), "pers": (20, 0), "pers_xcd2_u12": (20, 0x1200c00), "pers_xcd4_u6": (20, 0x1400600), "pers_xcd8_u3": (20, 0x1800300)}
+import ctypes
+from vitamd import lib as _l2
+_L = _l2.load()
+for a in sys.argv[1:]:                      # name=tile[:dbgbits]
+    k, v = a.split("="); t, _, d = v.partition(":"); cfgs[k] = (int(t, 0), int(d, 0) if d else 0)
 dev = torch.device("cuda")
 M, D = 256 * 197, 768
 g = torch.Generator(device="cpu").manual_seed(1)
@@ -31,7 +34,8 @@ for name, fn, fl in calls:
     ref = None
     res = {k: [] for k in cfgs}
     for rnd in range(5):
-        for k, t in cfgs.items():
+        for k, (t, dbg) in cfgs.items():
+            _L.vitamd_set_debug(dbg)
             out = fn(t)
             if rnd == 0:
                 torch.cuda.synchronize()
@@ -47,6 +51,7 @@ for name, fn, fl in calls:
             for _ in range(10): fn(t)
             e.record(); torch.cuda.synchronize()
             res[k].append(s.elapsed_time(e) / 10 * 1e3)
+            _L.vitamd_set_debug(0)
     for k in cfgs:
         med = statistics.median(res[k]); tot[k] += med
         print(f"{name:10s} {k:10s} {med:7.1f} us  {fl / med / 1e6:7.1f} TF  {['%.0f' % v for v in res[k]]}", flush=True)

@@ -152,7 +152,7 @@ struct PpSchedule {
   static constexpr int lookback = (LA > LB ? LA : LB);          // phases before the first whose requests the prologue replays
 };
 
-template <int EPI, int MT, int LA, int LB>
+template <int EPI, int MT, int LA, int LB, bool PERS = false>     // PERS (experimental builds): one workgroup per CU walks a strided list of tiles
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmNtArgs p) {
   constexpr int NP = MT / 2;
   static_assert(MT % 2 == 0 && LA >= 2 && LA <= 2 * NP - 2 && LB >= 5 && LB <= 2 * NP - 2, "request leads");
@@ -166,15 +166,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmNtArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int ntiles = tiles_m * tiles_n;
+  const int K = p.K;
+  const int nkt = K / 64;
+  const srd_t srdA = make_srd(p.A, (size_t)p.M * K * 2);
+  const srd_t srdB = make_srd(p.B, (size_t)p.N * K * 2);
+  if constexpr (PERS) {     // start-up stagger of the persistent form: dbg bits 20-23 = groups, bits 8-15 = delay per group in ~us
+    const int P = (VITAMD_DBG(p) >> 20) & 0xf, unit = (VITAMD_DBG(p) >> 8) & 0xff;
+    if (P > 1)
+      for (int i = 0; i < unit * (int)(((VITAMD_DBG(p) & (1 << 24)) ? (blockIdx.x & 7) : (blockIdx.x >> 3)) % P); ++i) __builtin_amdgcn_s_sleep(32);   // bit 24: whole XCDs share a group
+  }
+  for (int ti = blockIdx.x; ti < ntiles; ti += PERS ? (int)gridDim.x : ntiles) {
+  const int tile = xcd_remap(ti, ntiles);
   int tm, tn;
   tile_coords(tile, tiles_m, tiles_n, tiles_n >= 6, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int K = p.K;
-  const int nkt = K / 64;
-
-  const srd_t srdA = make_srd(p.A, (size_t)p.M * K * 2);
-  const srd_t srdB = make_srd(p.B, (size_t)p.N * K * 2);
   // this wave's piece of A-part j: LDS rows 8*wave + (lane>>3) of the part = rows 32 j + (lr&31) of wave row lr>>5;
   // its piece q of the B block: rows 64 q + 8*wave + (lane>>3).  16-B chunk lane&7, XOR (row&7) on the source side.
   unsigned voffA[NP], voffB[4];
@@ -279,17 +285,19 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmNtArgs p) {
   if constexpr (EPI == EPI_F32) gemm_epilogue<BN, 2, WN, 16 * MT, 64, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
   else if (p.N % 8 == 0 && p.ldo % 8 == 0) gemm_epilogue_rows<EPI, MT>(p, acc, m0, n0, wm, wn, lane, tid, wave, smem);
   else gemm_epilogue<BN, 2, WN, 16 * MT, 64, MT, NT, EPI>(p, acc, m0, n0, wm, wn, lane, tid, smem);
+  if constexpr (PERS) __syncthreads();              // every wave is done with its epilogue image before the next tile's DMA lands
+  }
 }
 
-template <int EPI, int MT, int LA, int LB>
+template <int EPI, int MT, int LA, int LB, bool PERS = false>
 int launch_pp(const GemmNtArgs& p, hipStream_t stream) {
   constexpr int BM = 32 * MT;
   constexpr int ops_b = 2 * ((MT / 2) * 8192 + 32768), epi_b = 8 * MT * 2048;     // operand buffers / epilogue images
   constexpr int lds = ops_b > epi_b ? ops_b : epi_b;
-  auto kern = gemm_nt_pp_kernel<EPI, MT, LA, LB>;
+  auto kern = gemm_nt_pp_kernel<EPI, MT, LA, LB, PERS>;
   if (int e = set_lds(kern, lds)) return e;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(PERS && tiles > 256 ? 256 : tiles), dim3(512), lds, stream, p);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
 
