@@ -15,7 +15,7 @@ def t(fn, n=10):
     torch.cuda.synchronize(); s.record()
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n * 1e3
-cfgs = {"two_kernel": 0, "fused": 0x200}
+cfgs = {"two_kernel": 0}
 for a in sys.argv[1:]:
     k, v = a.split("="); cfgs[k] = int(v, 0)
 res = {k: [] for k in cfgs}; fw = []; fw_old = []
@@ -35,4 +35,6 @@ o_old, lse_old = ops.attention_fwd(qkv, B, N, H)
 L.vitamd_set_debug(0x2000); o_new, lse_new = ops.attention_fwd(qkv, B, N, H); L.vitamd_set_debug(0); torch.cuda.synchronize()
 print("fwd persistent vs per-head: o equal", torch.equal(o_new, o_old), "lse equal", torch.equal(lse_new, lse_old))
 print(f"fwd persistent {statistics.median(fw):7.1f} us, per-head kernel {statistics.median(fw_old):7.1f} us   (HBM floor 52 us)")
+L.vitamd_set_debug(0x4000); one = statistics.median(t(lambda: ops.attention_fwd(qkv, B, N, H)) for _ in range(5)); L.vitamd_set_debug(0)
+print(f"fwd per-head kernel at ONE workgroup per CU: {one:7.1f} us")
 for k in cfgs: print(f"bwd {k:12s} {statistics.median(res[k]):7.1f} us  {['%.0f' % v for v in res[k]]}")

@@ -892,7 +892,7 @@ static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float
   } else
 #endif
   if (nkt <= 8) {
-    const int lds = 2 * npad * 128 + 4 * 4096;
+    const int lds = 2 * npad * 128 + 4 * 4096 + ((VITAMD_GDBG & 0x4000) ? 32768 : 0);      // (dbg bit 14, experimental builds: occupancy probe - one workgroup per CU)
     int e = VITAMD_OK;
 #define FWD_SMALL(K) case K: e = drop ? launch_fwd_small<K, true>(a, lds, stream) : launch_fwd_small<K, false>(a, lds, stream); break;
     switch (nkt) { FWD_SMALL(1) FWD_SMALL(2) FWD_SMALL(3) FWD_SMALL(4) FWD_SMALL(5) FWD_SMALL(6) FWD_SMALL(7) FWD_SMALL(8) }

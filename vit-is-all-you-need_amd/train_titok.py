@@ -74,17 +74,16 @@ class Quantizer(nn.Module):
         self.codebook.weight.data.uniform_(-1.0 / titok_config.codebook_size, 1.0 / titok_config.codebook_size)
 
     def forward(self, x):
-        x = torch.nn.functional.normalize(x, dim=-1)
+        """cosine-similarity VQ (behaviour of reference train_titok.py:50-59): tokens and codes are compared on the unit sphere,
+        the RAW code rows are what comes out; loss = |codes - sg(tokens)|^2 + 0.25 |sg(codes) - tokens|^2 (means); straight-through"""
+        unit = torch.nn.functional.normalize(x, dim=-1)
         with torch.no_grad():
-            embedding = torch.nn.functional.normalize(self.codebook.weight, dim=-1)
-            indices = ops.vq_nearest(x.detach().reshape(-1, x.shape[-1]).float().contiguous(),
-                                     embedding.float().contiguous()).view(x.shape[:-1])
-        quantized = self.codebook(indices)                      # the RAW codebook rows, as in the reference
-        codebook_loss = (quantized - x.detach()).pow(2).mean()
-        commitment_loss = 0.25 * (quantized.detach() - x).pow(2).mean()
-        quantize_loss = codebook_loss + commitment_loss
-        quantized = x + (quantized - x).detach()                # straight-through
-        return quantized, indices, quantize_loss
+            codes_unit = torch.nn.functional.normalize(self.codebook.weight, dim=-1).float().contiguous()
+            ids = ops.vq_nearest(unit.reshape(-1, unit.shape[-1]).float().contiguous(), codes_unit).view(unit.shape[:-1])
+        picked = self.codebook(ids)
+        sq = lambda t: t.pow(2).mean()
+        loss = sq(picked - unit.detach()) + 0.25 * sq(picked.detach() - unit)
+        return unit + (picked - unit).detach(), ids, loss
 
 
 class TiTokDecoder(nn.Module):
@@ -110,11 +109,18 @@ class TiTok(nn.Module):
         self.quant = Quantizer(titok_config)
         self.dec = TiTokDecoder(titok_config)
 
-    def encode(self, z): return self.quant(self.enc(z))[1]
-    def decode(self, z_quant): return self.dec(z_quant)
-    def decode_indices(self, indices): return self.dec(self.quant.codebook(indices))
+    def encode(self, z):
+        """image -> code ids [b, latent_tokens]"""
+        _, ids, _ = self.quant(self.enc(z))
+        return ids
+
+    def decode(self, z_quant):
+        return self.dec(z_quant)
+
+    def decode_indices(self, indices):
+        return self.dec(self.quant.codebook(indices))
 
     def forward(self, x):
-        latent_embs = self.enc(x)
-        quantized, indices, quantize_loss = self.quant(latent_embs)
-        return self.dec(quantized), indices, quantize_loss
+        """-> (reconstruction [b, 3, H, W], code ids, quantiser loss)"""
+        tokens, ids, qloss = self.quant(self.enc(x))
+        return self.dec(tokens), ids, qloss

@@ -60,11 +60,18 @@ class ViTVQGAN(nn.Module):
         self.quant = Quantizer(config)
         self.decoder = ViTVQGANDecoder(config)
 
-    def encode(self, z): return self.quant(self.encoder(z))[1]
-    def decode(self, z_quant): return self.decoder(z_quant)
-    def decode_indices(self, indices): return self.decoder(self.quant.codebook(indices))
+    def encode(self, z):
+        """image -> code ids [b, n_patches]"""
+        _, ids, _ = self.quant(self.encoder(z))
+        return ids
+
+    def decode(self, z_quant):
+        return self.decoder(z_quant)
+
+    def decode_indices(self, indices):
+        return self.decoder(self.quant.codebook(indices))
 
     def forward(self, x):
-        latent_embs = self.encoder(x)
-        quantized, indices, quantize_loss = self.quant(latent_embs)
-        return self.decoder(quantized), indices, quantize_loss
+        """-> (reconstruction [b, 3, H, W], code ids, quantiser loss)"""
+        tokens, ids, qloss = self.quant(self.encoder(x))
+        return self.decoder(tokens), ids, qloss
