@@ -192,7 +192,40 @@ struct AttnArgs {
   // (transformer.py:44 `x = x + attn(...)`), so the LayerNorm that follows reads x once instead of x and o and writing x
   const float* resid_in;
   float* resid_out;
+  int dbg;             // experimental builds: A/B bits (0 in production)
 };
+
+// Phase probe of experimental builds (dbg bit 15; tools/attn_phases.py): every wave sums the shader-clock cycles it spends in each
+// phase (a tick drains its own loads and waits for the accumulator named) and adds them to g_attn_probe at exit.
+#ifdef VITAMD_EXPERIMENTAL
+constexpr int PROBE_WAVES = 16384;
+__device__ unsigned long long g_attn_probe[2 * PROBE_WAVES * 8];   // [kernel slot][wave][phase]: one private row per wave (no atomics)
+#define PROBE_DECL                                                  \
+  const bool pr_on = VITAMD_DBG(a) & 0x8000;                        \
+  const unsigned long long pr_wall0 = pr_on ? wall_clock64() : 0ull;  \
+  unsigned long long pr_last = pr_on ? clock64() : 0ull, pr_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PROBE_TICK_(i, dep, WAITS)                                                         \
+  if (pr_on) {                                                                             \
+    const int d_ = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)(dep)));  \
+    asm volatile(WAITS ::"s"(d_) : "memory");                                              \
+    const unsigned long long t_ = clock64();                                               \
+    pr_acc[i] += t_ - pr_last;                                                             \
+    pr_last = t_;                                                                          \
+  }
+#define PROBE_TICK(i, dep) PROBE_TICK_(i, dep, "s_waitcnt vmcnt(0) lgkmcnt(0)")
+#define PROBE_TICK_NOVM(i, dep) PROBE_TICK_(i, dep, "s_waitcnt lgkmcnt(0)")
+#define PROBE_END(slot)                                                                               \
+  if (pr_on && lane == 0 && blockIdx.x * 4 + wave < PROBE_WAVES) {                                    \
+    unsigned long long* row_ = g_attn_probe + ((size_t)(slot) * PROBE_WAVES + blockIdx.x * 4 + wave) * 8; \
+    for (int i_ = 0; i_ < 6; ++i_) row_[i_] = pr_acc[i_];                                            \
+    row_[6] = 1ull;                                                                                   \
+  }
+#else
+#define PROBE_DECL
+#define PROBE_TICK(i, dep)
+#define PROBE_TICK_NOVM(i, dep)
+#define PROBE_END(slot)
+#endif
 
 // keep-scale of probability (b, head, query, key): 1/(1-p) or 0
 __device__ __forceinline__ float attn_keep(const AttnArgs& a, int bh, int query, int key) {
@@ -282,7 +315,9 @@ template <int NKT, bool DROP, bool CAUSAL, bool RES = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x / a.H, hh = blockIdx.x % a.H;
+  PROBE_DECL
+  const int head = blockIdx.x;     // one workgroup per (batch, head); a persistent two-per-CU grid walking the heads is slower (backward 276 against 256 us)
+  const int b = head / a.H, hh = head % a.H;
   const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
   constexpr int nt = NKT, npad = NKT * 32;
   char* ktile = smem;
@@ -291,16 +326,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
   const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
   stage_tile(qbase + D, D3, N, npad, ktile, wave, lane);
   stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane);
+  const int wrot = (wave + head) & 3;   // rotate which wave gets the short list of query blocks
+  // the Q rows of both of this wave's query blocks ride the same wait as the K/V staging (one memory round trip per head, not three)
+  bf16x8 qf[4], qf2[4];
+  load_lane_frags(qbase, D3, N, wrot * 32, lane, qf);
+  if (wrot + 4 < nt) load_lane_frags(qbase, D3, N, wrot * 32 + 128, lane, qf2);
+  else {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf2[kk] = qf[kk];
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(qf[kk]), "+v"(qf2[kk]));   // pins the loads above the wait (hipcc sinks plain loads to their first use)
   __syncthreads();
+  PROBE_TICK(0, 0.f)
 
   const float c = a.scale_log2e;
-  const int wrot = (wave + blockIdx.x) & 3;   // rotate which wave gets the short list of query blocks
   for (int qb = wrot; qb < nt; qb += 4) {
     const int q0 = qb * 32;
     const int qrow = q0 + (lane & 31);
-    bf16x8 qf[4];
-    load_lane_frags(qbase, D3, N, q0, lane, qf);
+    if (qb != wrot) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = qf2[kk];
+    }
     const int t_end = CAUSAL ? qb + 1 : nt;
     f32x16 s[NKT];
     float mx = NEG_BIG;
@@ -322,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    PROBE_TICK(2, mx)
     const float mc = mx * c;
     float l = 0.f;
     f32x16 oacc[2];
@@ -336,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
         for (int r = 0; r < 16; ++r) {
           float pexp = fast_exp2(__builtin_fmaf(s[T][r], c, -mc));
           l += pexp;
-          if constexpr (DROP) pexp *= attn_keep(a, blockIdx.x, min(qrow, N - 1), min(32 * T + acc_row(r, lane), N - 1));
+          if constexpr (DROP) pexp *= attn_keep(a, head, min(qrow, N - 1), min(32 * T + acc_row(r, lane), N - 1));
           s[T][r] = pexp;
         }
 #pragma unroll
@@ -349,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
       }
     }
     l += __shfl_xor(l, 32, 64);
+    PROBE_TICK(3, l + oacc[0][15] + oacc[1][15])
     const float inv = 1.0f / l;
     if constexpr (RES)
       store_rows_T_lds_resid(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg, a.resid_in + (size_t)b * N * D + hh * DH,
@@ -356,7 +406,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
     else
       store_rows_T_lds(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg);
     if (lane < 32 && qrow < N) a.lse2[((size_t)b * a.H + hh) * N + qrow] = mc + log2f(l);
+    PROBE_TICK_NOVM(4, 0.f)
   }
+#ifdef VITAMD_EXPERIMENTAL
+  if (pr_on) pr_acc[5] = wall_clock64() - pr_wall0;      // 100-MHz wall clock over the wave's life: calibrates the cycle counter
+#endif
+  PROBE_END(0)
 }
 
 #ifdef VITAMD_EXPERIMENTAL
@@ -375,10 +430,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   char* vtile = smem + npad * 128;
   char* oimg = smem + 2 * npad * 128 + wave * 4096;
   const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  PROBE_DECL
   stage_tile(qbase + D, D3, N, npad, ktile, wave, lane);
   stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  PROBE_TICK(0, 0.f)
 
   const float c = a.scale_log2e;
   const __bf16* obase = a.o + (size_t)b * N * D + hh * DH;
@@ -400,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const size_t stat = ((size_t)b * a.H + hh) * N + min(qrow, N - 1);
     const float lse2 = a.lse2[stat];
     if (lane < 32 && qrow < N) a.delta[stat] = delta;
+    PROBE_TICK(1, delta + lse2)
 
     f32x16 dq[2];
 #pragma unroll
@@ -416,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vtile, T, kk, lane), dof[kk], dp, 0, 0, 0);
       }
+      PROBE_TICK(2, s[15] + dp[15])
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pexp = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
@@ -430,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
           if (!(key < N && (!CAUSAL || key <= qrow))) s[r] = 0.f;
         }
       }
+      PROBE_TICK(3, s[0] + s[15])
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
         const bf16x8 dsf = acc_to_frag(s, sidx);
@@ -437,10 +497,131 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         for (int dt = 0; dt < 2; ++dt)
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ktile, T, sidx, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
+      PROBE_TICK(4, dq[0][15] + dq[1][15])
     }
     store_rows_T_lds(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale, oimg, a.dbias ? &csum_q : nullptr);
+    PROBE_TICK_NOVM(5, 0.f)
   }
   if (a.dbias) atomicAdd(a.dbias + hh * DH + lane, csum_q);   // 256 contiguous bytes per wave
+  PROBE_END(0)
+}
+
+// ------------------------------------------------------------------------------------------ backward, dQ: software-pipelined form
+// The loop above leaves the schedule to hipcc, which reads every LDS fragment right in front of the MFMA that consumes it and
+// keeps the three stages of a key tile (S/dP products, exp + dS on the VALU, dQ products) strictly one after the other: the phase
+// probe (tools/attn_phases.py) shows 1 660 cycles per tile against ~400 of matrix-pipe and ~300 of VALU work.  Here the tile count
+// is a template parameter, the loop is unrolled and the stages of neighbouring tiles overlap by construction:
+//   iteration T:  request K/V row fragments of tile T+2 and the transposed K fragments of tile T
+//                 S, dP products of tile T+1 (fragments requested one iteration earlier)   } one scheduling region: hipcc interleaves
+//                 exp, dS of tile T on the VALU                                            } the independent MFMA and VALU streams
+//                 dQ += K^T.dS of tile T
+// Same arithmetic in the same order as attn_bwd_dq_kernel (bit-identical results); non-causal, no dropout.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  PROBE_DECL
+  const int head = blockIdx.x;     // one workgroup per (batch, head); a persistent two-per-CU grid walking the heads is slower (backward 276 against 256 us)
+  const int b = head / a.H, hh = head % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  constexpr int nt = NT, npad = NT * 32;
+  char* ktile = smem;
+  char* vtile = smem + npad * 128;
+  char* oimg = smem + 2 * npad * 128 + wave * 4096;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  stage_tile(qbase + D, D3, N, npad, ktile, wave, lane);
+  stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane);
+  const __bf16* obase = a.o + (size_t)b * N * D + hh * DH;
+  const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  PROBE_TICK(0, 0.f)
+
+  const float c = a.scale_log2e;
+  float csum_q = 0.f;
+  // (requesting the first block's Q, dO, O rows together with the K/V staging makes this kernel slower, 272 against 259 us per
+  // backward: more requests in flight only queue longer - the forward, with a third of the lane-side traffic, gains 5 % from it)
+  for (int qb = (wave + head) & 3; qb < nt; qb += 4) {
+    const int q0 = qb * 32;
+    const int qrow = q0 + (lane & 31);
+    bf16x8 qf[4], dof[4];
+    float delta = 0.f;
+    {
+      bf16x8 of[4];
+      load_lane_frags(qbase, D3, N, q0, lane, qf);
+      load_lane_frags(dobase, D, N, q0, lane, dof);
+      load_lane_frags(obase, D, N, q0, lane, of);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += (float)dof[kk][j] * (float)of[kk][j];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const size_t stat = ((size_t)b * a.H + hh) * N + min(qrow, N - 1);
+    const float lse2 = a.lse2[stat];
+    if (lane < 32 && qrow < N) a.delta[stat] = delta;
+    PROBE_TICK(1, delta + lse2)
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    bf16x8 kr[2][4], vr[2][4];      // row fragments of K and V, two tiles in flight
+    f32x16 sb[2], dpb[2];           // S^T and dP^T of the tile on the VALU and of the next one in the matrix pipe
+    auto products = [&](int buf) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sb[buf][r] = 0.f; dpb[buf][r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        sb[buf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[buf][kk], qf[kk], sb[buf], 0, 0, 0);
+        dpb[buf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[buf][kk], dof[kk], dpb[buf], 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { kr[0][kk] = row_frag(ktile, 0, kk, lane); vr[0][kk] = row_frag(vtile, 0, kk, lane); }
+    if (NT > 1) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { kr[1][kk] = row_frag(ktile, 1, kk, lane); vr[1][kk] = row_frag(vtile, 1, kk, lane); }
+    }
+    products(0);
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      const int cur = T & 1, nxt = cur ^ 1;
+      bf16x8 ktr[2][2];
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) ktr[sidx][dt] = tr_frag(ktile, T, sidx, dt, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (T + 1 < NT) products(nxt);
+      if (T + 2 < NT) {             // tile T's row fragments were consumed by the products issued one iteration ago
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { kr[cur][kk] = row_frag(ktile, T + 2, kk, lane); vr[cur][kk] = row_frag(vtile, T + 2, kk, lane); }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pexp = fast_exp2(__builtin_fmaf(sb[cur][r], c, -lse2));
+        sb[cur][r] = pexp * (dpb[cur][r] - delta);  // dS^T (the 1/sqrt(dh) factor is applied once at the end)
+      }
+      if (T == NT - 1 && 32 * T + 32 > N) {         // boundary tile: zero the masked keys
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!(32 * T + acc_row(r, lane) < N)) sb[cur][r] = 0.f;
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 dsf = acc_to_frag(sb[cur], sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr[sidx][dt], dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    PROBE_TICK(2, dq[0][15] + dq[1][15])
+    store_rows_T_lds(a.dqkv + (size_t)b * N * D3 + hh * DH, D3, N, q0, lane, dq, a.scale, oimg, a.dbias ? &csum_q : nullptr);
+    PROBE_TICK_NOVM(5, 0.f)
+  }
+  if (a.dbias) atomicAdd(a.dbias + hh * DH + lane, csum_q);   // 256 contiguous bytes per wave
+  PROBE_END(0)
 }
 
 // ------------------------------------------------------------------------------------------ backward, dK and dV
@@ -458,6 +639,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
   char* oimg = smem + 2 * npad * 128 + 2 * npad * 4 + wave * 4096;
   const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
   const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  PROBE_DECL
   stage_tile(qbase, D3, N, npad, qtile, wave, lane);
   stage_tile(dobase, D, N, npad, dotile, wave, lane);
   for (int i = threadIdx.x; i < npad; i += 256) {
@@ -467,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  PROBE_TICK(0, 0.f)
 
   const float c = a.scale_log2e;
   float csum_k = 0.f, csum_v = 0.f;
@@ -476,6 +659,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     bf16x8 kf[4], vf[4];
     load_lane_frags(qbase + D, D3, N, k0, lane, kf);
     load_lane_frags(qbase + 2 * D, D3, N, k0, lane, vf);
+    PROBE_TICK(1, (float)kf[3][7] + (float)vf[3][7])
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -491,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, T, kk, lane), kf[kk], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, T, kk, lane), vf[kk], dp, 0, 0, 0);
       }
+      PROBE_TICK(2, s[15] + dp[15])
       f32x16 pmat;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -514,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
           }
         }
       }
+      PROBE_TICK(3, s[0] + pmat[15])
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
         const bf16x8 pf = acc_to_frag(pmat, sidx);
@@ -524,15 +710,135 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
           dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, T, sidx, dt, lane), dsf, dk[dt], 0, 0, 0);
         }
       }
+      PROBE_TICK(4, dk[1][15] + dv[1][15])
     }
     __bf16* dbase = a.dqkv + (size_t)b * N * D3 + hh * DH;
     store_rows_T_lds(dbase + D, D3, N, k0, lane, dk, a.scale, oimg, a.dbias ? &csum_k : nullptr);
     store_rows_T_lds(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f, oimg, a.dbias ? &csum_v : nullptr);
+    PROBE_TICK_NOVM(5, 0.f)
   }
   if (a.dbias) {
     atomicAdd(a.dbias + D + hh * DH + lane, csum_k);
     atomicAdd(a.dbias + 2 * D + hh * DH + lane, csum_v);
   }
+  PROBE_END(1)
+}
+
+// ------------------------------------------------------------------------------------------ backward, dK and dV: software-pipelined form
+// Same restructuring as attn_bwd_dq_pipe_kernel (tile count a template parameter, unrolled, LDS fragments requested a stage
+// ahead, the S/dP products of query tile T+1 issued before the VALU work of tile T).  Padded query rows need no masking here:
+// their lse is staged as +1e30, so P and dS are exactly 0 for them; padded key lanes are never stored.  Bit-identical to
+// attn_bwd_dkv_kernel; non-causal, no dropout.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pipe_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  PROBE_DECL
+  const int head = blockIdx.x;     // one workgroup per (batch, head); a persistent two-per-CU grid walking the heads is slower (backward 276 against 256 us)
+  const int b = head / a.H, hh = head % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  constexpr int nt = NT, npad = NT * 32;
+  char* qtile = smem;
+  char* dotile = smem + npad * 128;
+  float* lse_s = (float*)(smem + 2 * npad * 128);
+  float* delta_s = lse_s + npad;
+  char* oimg = smem + 2 * npad * 128 + 2 * npad * 4 + wave * 4096;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  const __bf16* dobase = a.d_o + (size_t)b * N * D + hh * DH;
+  stage_tile(qbase, D3, N, npad, qtile, wave, lane);
+  stage_tile(dobase, D, N, npad, dotile, wave, lane);
+  for (int i = threadIdx.x; i < npad; i += 256) {
+    const size_t stat = ((size_t)b * a.H + hh) * N + min(i, N - 1);
+    lse_s[i] = i < N ? a.lse2[stat] : 1.0e30f;        // padded queries: exp2(s - 1e30) = 0 exactly
+    delta_s[i] = a.delta[stat];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  PROBE_TICK(0, 0.f)
+
+  const float c = a.scale_log2e;
+  float csum_k = 0.f, csum_v = 0.f;
+  for (int kb = (wave + head) & 3; kb < nt; kb += 4) {
+    const int k0 = kb * 32;
+    bf16x8 kf[4], vf[4];
+    load_lane_frags(qbase + D, D3, N, k0, lane, kf);
+    load_lane_frags(qbase + 2 * D, D3, N, k0, lane, vf);
+    PROBE_TICK(1, (float)kf[3][7] + (float)vf[3][7])
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    bf16x8 qr[4], dor[4];           // row fragments of Q and dO of the tile whose products are issued next
+    f32x16 sb, dpb;                 // (one set: 256 registers do not hold a second one next to dK, dV and the fragments)
+    auto products = [&]() {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dpb[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[kk], kf[kk], sb, 0, 0, 0);
+        dpb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dor[kk], vf[kk], dpb, 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { qr[kk] = row_frag(qtile, 0, kk, lane); dor[kk] = row_frag(dotile, 0, kk, lane); }
+    products();
+    if (NT > 1) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { qr[kk] = row_frag(qtile, 1, kk, lane); dor[kk] = row_frag(dotile, 1, kk, lane); }
+    }
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      bf16x8 dotr[2][2], qtr[2][2];
+      f32x4 lse4[4], del4[4];
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) { dotr[sidx][dt] = tr_frag(dotile, T, sidx, dt, lane); qtr[sidx][dt] = tr_frag(qtile, T, sidx, dt, lane); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qr0 = 32 * T + 8 * u + 4 * (lane >> 5);
+        lse4[u] = *(const f32x4*)(lse_s + qr0);
+        del4[u] = *(const f32x4*)(delta_s + qr0);
+      }
+      f32x16 pmat;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * u + i;
+          const float pexp = fast_exp2(__builtin_fmaf(sb[r], c, -lse4[u][i]));
+          pmat[r] = pexp;
+          sb[r] = pexp * (dpb[r] - del4[u][i]);
+        }
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const bf16x8 pf = acc_to_frag(pmat, sidx);
+        const bf16x8 dsf = acc_to_frag(sb, sidx);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotr[sidx][dt], pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr[sidx][dt], dsf, dk[dt], 0, 0, 0);
+        }
+      }
+      if (T + 1 < NT) products();     // S, dP of the next tile queue up behind this tile's dV, dK products
+      if (T + 2 < NT) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { qr[kk] = row_frag(qtile, T + 2, kk, lane); dor[kk] = row_frag(dotile, T + 2, kk, lane); }
+      }
+    }
+    PROBE_TICK(2, dk[1][15] + dv[1][15])
+    __bf16* dbase = a.dqkv + (size_t)b * N * D3 + hh * DH;
+    store_rows_T_lds(dbase + D, D3, N, k0, lane, dk, a.scale, oimg, a.dbias ? &csum_k : nullptr);
+    store_rows_T_lds(dbase + 2 * D, D3, N, k0, lane, dv, 1.0f, oimg, a.dbias ? &csum_v : nullptr);
+    PROBE_TICK_NOVM(5, 0.f)
+  }
+  if (a.dbias) {
+    atomicAdd(a.dbias + D + hh * DH + lane, csum_k);
+    atomicAdd(a.dbias + 2 * D + hh * DH + lane, csum_v);
+  }
+  PROBE_END(1)
 }
 
 #ifdef VITAMD_EXPERIMENTAL
@@ -863,7 +1169,7 @@ static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float
   hipStream_t stream = (hipStream_t)stream_;
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
   AttnArgs a{(const __bf16*)qkv, (__bf16*)o, lse2, nullptr, nullptr, nullptr, nullptr, B, N, H, causal, 0.125f * 1.4426950408889634f, 0.125f,
-             0u, 1.0f, 0u, 0u, resid_in, resid_out};
+             0u, 1.0f, 0u, 0u, resid_in, resid_out, VITAMD_GDBG};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2 || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
   const bool drop = a.drop_thresh != 0u;
@@ -917,7 +1223,7 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
   hipStream_t stream = (hipStream_t)stream_;
   if (head_dim != DH) return VITAMD_ERR_SHAPE;
   AttnArgs a{(const __bf16*)qkv, (__bf16*)o, (float*)lse2, (const __bf16*)d_o, (__bf16*)dqkv, delta, dbias, B, N, H, causal,
-             0.125f * 1.4426950408889634f, 0.125f, 0u, 1.0f, 0u, 0u, nullptr, nullptr};
+             0.125f * 1.4426950408889634f, 0.125f, 0u, 1.0f, 0u, 0u, nullptr, nullptr, VITAMD_GDBG};
   if (int e = check(a)) return e;
   if (!qkv || !o || !lse2 || !d_o || !dqkv || !delta || !attn_dropout(a, dropout_p, seed)) return VITAMD_ERR_ARG;
   if (N > MAX_N) {
@@ -953,6 +1259,19 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
 #endif
   const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
   const dim3 grid(B * H), block(256);
+  const int nkt = npad / 32;
+  if (!a.drop_thresh && !a.causal && nkt >= 2 && nkt <= 8 && !(VITAMD_GDBG & 0x20000)) {     // the ViT shapes: pipelined forms (dbg bit 17 of experimental builds: the plain loops)
+    int e = VITAMD_OK;
+#define DQ_PIPE(K) case K: e = set_lds(attn_bwd_dq_pipe_kernel<K>, lds1); if (!e) hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel<K>, grid, block, lds1, stream, a); break;
+    switch (nkt) { DQ_PIPE(2) DQ_PIPE(3) DQ_PIPE(4) DQ_PIPE(5) DQ_PIPE(6) DQ_PIPE(7) DQ_PIPE(8) }
+#undef DQ_PIPE
+    if (e) return e;
+#define DKV_PIPE(K) case K: e = set_lds(attn_bwd_dkv_pipe_kernel<K>, lds2); if (!e) hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<K>, grid, block, lds2, stream, a); break;
+    switch (nkt) { DKV_PIPE(2) DKV_PIPE(3) DKV_PIPE(4) DKV_PIPE(5) DKV_PIPE(6) DKV_PIPE(7) DKV_PIPE(8) }
+#undef DKV_PIPE
+    if (e) return e;
+    return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+  }
 #define BWD_SMALL(DROP, CAUSAL)                                                                      \
   do {                                                                                               \
     if (int e = set_lds((attn_bwd_dq_kernel<DROP, CAUSAL>), lds1)) return e;                         \
@@ -965,3 +1284,20 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
 #undef BWD_SMALL
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
+
+#ifdef VITAMD_EXPERIMENTAL
+// experimental library only: sum (and clear) the per-wave phase-probe rows into out[16] = two kernel slots x (6 phases, waves, -)
+extern "C" int vitamd_debug_attn_probe(unsigned long long* out) {
+  static unsigned long long host[2 * PROBE_WAVES * 8];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_probe), sizeof(host)) != hipSuccess) return VITAMD_ERR_LAUNCH;
+  for (int k = 0; k < 2; ++k)
+    for (int j = 0; j < 8; ++j) {
+      unsigned long long t = 0;
+      for (int w = 0; w < PROBE_WAVES; ++w) t += host[((size_t)k * PROBE_WAVES + w) * 8 + j];
+      out[k * 8 + j] = t;
+    }
+  void* dptr = nullptr;
+  if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_attn_probe)) != hipSuccess) return VITAMD_ERR_LAUNCH;
+  return hipMemset(dptr, 0, sizeof(host)) == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+}
+#endif
