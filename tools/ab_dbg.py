@@ -1,10 +1,12 @@
-"""A/B of vitamd_set_debug knobs on the whole training step (interleaved, medians).  usage: ab_dbg.py name=bits ..."""
+"""A/B of vitamd_set_debug knobs on the whole training step (interleaved, medians).  usage: ab_dbg.py name=bits ...
+(AB_NO_SIDE=1 in the environment: weight-gradient GEMMs on the main stream)"""
 import os, sys, time, statistics, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 import train_vit as TV
 from vitamd import functions as F, lib
 lib.use_experimental(); L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+if os.environ.get("AB_NO_SIDE") == "1": F.SIDE.enabled = False
 cfgs = {"production": 0}
 for a in sys.argv[1:]:
     k, v = a.split("="); cfgs[k] = int(v, 0)
