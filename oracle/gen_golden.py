@@ -325,6 +325,46 @@ def gen_blocks_fixture():
     save("blocks_tiny.pt", out)
 
 
+DEPTH_STRIDE = 13    # parameter gradients: vectors in full, matrices as norm + every 13th element (the full set would be 9.6 MB)
+DEPTH_CASE = dict(depth=12, dim=128, num_heads=2, qkv_bias=True, tokens=197, batch=2, seed=77)
+
+
+def gen_blocks_depth_fixture():
+    """VERDICT r1 'missing' item 4: blocks.Attention upcasts q, k, v to fp32 before SDPA (reference blocks.py:100) while the build's
+    attention kernels work on bf16 operands.  The tiny per-block golden cannot show whether that matters at depth, so this fixture
+    runs a STACK of the reference's UViTBlocks (fp32 CPU, and under bf16 autocast - where the reference's SDPA still runs in fp32)
+    and records the output, the input gradient and every parameter gradient (norm + strided sample)."""
+    import blocks as RB
+    c = DEPTH_CASE
+    blocks = [RB.UViTBlock(dim=c["dim"], num_heads=c["num_heads"], qkv_bias=c["qkv_bias"]) for _ in range(c["depth"])]
+    shapes = {k: list(v.shape) for k, v in blocks[0].state_dict().items()}
+    for i, m in enumerate(blocks):
+        m.load_state_dict(W.module_state(c["seed"] + i, shapes), strict=True)
+    x = W.normal(c["seed"], "x", (c["batch"], c["tokens"], c["dim"])).requires_grad_(True)
+    dy = W.normal(c["seed"], "dy", tuple(x.shape))
+
+    def run(bf16):
+        x.grad = None
+        for m in blocks:
+            m.zero_grad(set_to_none=True)
+        h = x
+        if bf16:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                for m in blocks:
+                    h = m(h)
+        else:
+            for m in blocks:
+                h = m(h)
+        (h.float() * dy).sum().backward()
+        grads = {f"{i}.{k}": p.grad.detach().clone() for i, m in enumerate(blocks) for k, p in m.named_parameters()}
+        return h.detach().float(), x.grad.clone(), grads
+
+    y, dx, grads = run(False)
+    y16, dx16, g16 = run(True)
+    save("blocks_depth.pt", {"case": dict(c), "shapes": shapes, "y": y, "dx": dx, "grads": {k: {"norm": float(v.double().norm()), "sample": (v.flatten() if v.numel() <= 1024 else v.flatten()[::DEPTH_STRIDE]).clone()} for k, v in grads.items()},
+                             "ref_bf16_floor": {"y": rel_l2(y16, y), "dx": rel_l2(dx16, dx), "grads": {k: rel_l2(g16[k], grads[k]) for k in grads}}})
+
+
 TOK_CFG = dict(image_size=32, patch_size=8, transformer="small", latent_tokens=8, latent_dim=12, text_context_length=5, text_embed_dim=64)
 VQ_CASES = {
     # name: (ctor kwargs, z shape)
@@ -446,6 +486,9 @@ def main():
     if "--autocast-only" in sys.argv:          # add the round-2 fixture without touching the others
         gen_autocast_fixture(RT, TV)
         return
+    if "--blocks-depth-only" in sys.argv:
+        gen_blocks_depth_fixture()
+        return
     gen_autocast_fixture(RT, TV)
     gen_transformer_fixtures(RT)
     gen_classifier_fixture(TV, "vit_s32.pt", 32, "S", 10, 64, seed=13, full_grads=True)   # BASELINE config 1
@@ -454,6 +497,7 @@ def main():
     gen_train_steps_fixture(TV, RU)
     gen_tokenizer_fixtures()
     gen_blocks_fixture()
+    gen_blocks_depth_fixture()
     gen_block_tokenizer_fixture()
 
 
