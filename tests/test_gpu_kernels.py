@@ -260,7 +260,10 @@ def _attn_ref(qkv, B, N, H, causal, d_o=None):
 
 
 @pytest.mark.parametrize("B,N,H,causal", [(2, 5, 2, False), (1, 32, 1, False), (3, 37, 2, True), (2, 197, 3, False),
-                                          (1, 288, 2, False), (2, 64, 2, True), (1, 197, 2, True), (1, 512, 1, False)])
+                                          (1, 288, 2, False), (2, 64, 2, True), (1, 197, 2, True), (1, 512, 1, False),
+                                          # every tile count of the pipelined backward kernels (33 <= N <= 256, non-causal), ragged and exact
+                                          (2, 33, 1, False), (1, 64, 2, False), (2, 96, 1, False), (1, 130, 2, False), (1, 160, 1, False),
+                                          (1, 224, 1, False), (2, 256, 2, False)])
 def test_attention_fwd_bwd(hip, B, N, H, causal):
     from vitamd import ops
     qkv = r16(randn((B * N, 3 * H * 64), 31 + N, 1.5))

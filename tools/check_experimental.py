@@ -75,5 +75,16 @@ for (B, N, H, causal) in [(3, 197, 4, False), (2, 65, 2, True), (2, 256, 2, Fals
     err = float((got - ref).norm() / ref.norm())
     if not err < 1e-3:
         bad.append(("attn-fused", B, N, H, causal, err))
+# the software-pipelined attention backward kernels (production, 33 <= N <= 256 non-causal) against the plain loops (bit 17): bit-identical
+for (B, N, H) in [(2, 33, 2), (3, 64, 1), (2, 100, 3), (1, 160, 2), (2, 197, 4), (1, 224, 2), (2, 256, 1)]:
+    g = torch.Generator().manual_seed(10 + N)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g).to(dev, BF16); d_o = torch.randn(B * N, H * 64, generator=g).to(dev, BF16)
+    o, lse = ops.attention_fwd(qkv, B, N, H, False)
+    db = torch.zeros(3 * H * 64, device=dev); got = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, False, dbias=db)
+    L.vitamd_set_debug(0x20000)
+    db2 = torch.zeros(3 * H * 64, device=dev); ref = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, False, dbias=db2)
+    L.vitamd_set_debug(0)
+    if not torch.equal(got, ref) or not torch.allclose(db, db2, rtol=1e-5, atol=1e-5):
+        bad.append(("attn-bwd-pipe", B, N, H))
 print("experimental checks:", "ok" if not bad else bad)
 sys.exit(1 if bad else 0)
