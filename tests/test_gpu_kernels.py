@@ -336,6 +336,23 @@ def test_attention_softmax_spike(hip):
     assert O.rel_l2(o.float().cpu(), o_ref) < 1.0e-6
 
 
+def test_batched_weight_cast_vector_and_scalar_paths(hip):
+    """One launch casts (and transposes) every weight of a model: the 16-B path (N, K multiples of 4) and the scalar tail path
+    must both equal torch's own rounding, tile edges included."""
+    from vitamd.functions import WeightCache
+    ws = [randn(s, 60 + i).to(dev()) for i, s in enumerate(((768, 768), (2304, 768), (1000, 768), (100, 36), (70, 130), (33, 7), (64, 64), (4, 4)))]
+    for want_t in (True, False):
+        cache = WeightCache()
+        cache.prepare(ws, want_t)
+        torch.cuda.synchronize()
+        for w in ws:
+            wb, wbt = cache.get(w, want_t)
+            assert torch.equal(wb, w.to(BF16))
+            assert (wbt is None) == (not want_t)
+            if want_t:
+                assert torch.equal(wbt, w.t().contiguous().to(BF16))
+
+
 # ------------------------------------------------------------------------------------------ helpers
 def test_cast_transpose_im2col_colsum_embed(hip):
     from vitamd import ops

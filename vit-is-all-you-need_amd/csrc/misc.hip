@@ -73,6 +73,32 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const CastD
   const CastDesc d = desc[which];
   const int t = blockIdx.x - d.first_tile;
   const int n0 = (t / d.tiles_k) * 64, k0 = (t % d.tiles_k) * 64;
+  if ((d.K & 3) == 0 && (d.N & 3) == 0) {
+    // vector path (every weight of the models here): 16-B fp32 loads, 8-B bf16 stores in both orientations
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * 256 + threadIdx.x, r = idx >> 4, c = (idx & 15) * 4;
+      const int nn = n0 + r, k = k0 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (nn < d.N && k < d.K) {        // K % 4 == 0: the four columns are in range together
+        v = *(const f32x4*)(d.w + (size_t)nn * d.K + k);
+        if (d.wb) *(u32x2*)(d.wb + (size_t)nn * d.K + k) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[r][c + j] = v[j];
+    }
+    __syncthreads();
+    if (d.wbt) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + threadIdx.x, kl = idx >> 4, c = (idx & 15) * 4;
+        const int k = k0 + kl, nn = n0 + c;
+        if (k < d.K && nn < d.N)
+          *(u32x2*)(d.wbt + (size_t)k * d.N + nn) = u32x2{pack_bf16x2(tile[c][kl], tile[c + 1][kl]), pack_bf16x2(tile[c + 2][kl], tile[c + 3][kl])};
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {
     const int nn = n0 + r, k = k0 + tx;
