@@ -81,9 +81,8 @@ class DataParallel(torch.nn.Module):
                 dist.broadcast(t.data, src=0, group=process_group)
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets, cur, size = [], [], 0
-        # transformer stacks get one bucket per layer, in the exact (dWqkv, dbqkv, dW1, db1, dW2, db2)
-        # order of the kernels' gradient arena: their backward writes into the bucket directly and
-        # starts the all-reduce per layer (functions.GradSink)
+        # transformer stacks get one bucket per layer holding the six gradients the kernels' arena has (dWqkv, dbqkv, dW1, db1, dW2, db2),
+        # matrices first: their backward writes into the bucket directly and starts the all-reduce per layer (functions.GradSink)
         self._stack_layers = {}
         in_stack = set()
         try:
@@ -93,7 +92,8 @@ class DataParallel(torch.nn.Module):
                     key = tuple(id(p) for layer in m.layers for p in layer._params())
                     layer_buckets = []
                     for layer in m.layers:
-                        lp = list(layer._params())
+                        lp = list(layer._params())          # (Wqkv, bqkv, W1, b1, W2, b2)
+                        lp = [lp[0], lp[2], lp[4], lp[1], lp[3], lp[5]]   # bucket order: the three matrices, then the three bias vectors
                         layer_buckets.append(_Bucket(lp, lp[0].device))
                         in_stack.update(id(p) for p in lp)
                     self._stack_layers[key] = layer_buckets
@@ -167,9 +167,9 @@ class DataParallel(torch.nn.Module):
             return None               # accumulation, or .grad already aliases the bucket (zero_grad(set_to_none=False))
         out = []
         for b in lb:
-            b.flat.zero_()            # the kernels accumulate (atomics / column sums) into the bucket
+            b.flat[b.offsets[3]:].zero_()     # the kernels OVERWRITE the weight gradients and accumulate (atomics / column sums) only into the bias gradients at the bucket's tail
             b.launched = True
-            out.append(tuple(b.view(i) for i in range(6)))
+            out.append((b.view(0), b.view(3), b.view(1), b.view(4), b.view(2), b.view(5)))   # back in (dWqkv, dbqkv, dW1, db1, dW2, db2) order
         return out
 
     def layer_ready(self, params, i):
