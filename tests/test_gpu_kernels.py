@@ -366,11 +366,12 @@ def test_cast_transpose_im2col_colsum_embed(hip):
         assert torch.equal(ops.im2col(img.to(dev()), p).float().cpu(), r16(O.patchify(img, p)).reshape(-1, C * p * p))
     m = r16(randn((5000, 770), 44))
     assert O.rel_l2(ops.colsum(m.to(dev(), BF16)).cpu(), m.sum(0)) < 1e-5
-    B, seq, extra, D = 7, 11, 2, 256
-    g = randn((B * seq, D), 45)
-    dpos, dextra, dyp, dbias = ops.embed_bwd(g.to(dev()), B, seq, extra, D)
-    g3 = g.view(B, seq, D)
-    assert O.rel_l2(dpos.cpu(), g3[:, extra:].sum(0)) < 1e-6
-    assert O.rel_l2(dextra.cpu(), g3[:, :extra].sum(0)) < 1e-6
-    assert torch.equal(dyp.float().cpu(), r16(g3[:, extra:]).reshape(-1, D))
-    assert O.rel_l2(dbias.cpu(), r16(g3[:, extra:]).sum((0, 1))) < 1.0e-6
+    for B, seq, extra, D in ((7, 11, 2, 256), (40, 197, 1, 768), (3, 9, 0, 512), (5, 6, 2, 66)):      # 66: the scalar path (D % 4 != 0)
+        g = randn((B * seq, D), 45 + D)
+        dpos, dextra, dyp, dbias = ops.embed_bwd(g.to(dev()), B, seq, extra, D)
+        g3 = g.view(B, seq, D)
+        assert O.rel_l2(dpos.cpu(), g3[:, extra:].sum(0)) < 1e-6
+        if extra:
+            assert O.rel_l2(dextra.cpu(), g3[:, :extra].sum(0)) < 1e-6
+        assert torch.equal(dyp.float().cpu(), r16(g3[:, extra:]).reshape(-1, D))
+        assert O.rel_l2(dbias.cpu(), r16(g3[:, extra:]).sum((0, 1))) < 1.0e-6

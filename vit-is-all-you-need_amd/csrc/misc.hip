@@ -203,6 +203,30 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   const int t = blockIdx.x;  // token position
   const int b_lo = blockIdx.y * bchunk, b_hi = min(B, b_lo + bchunk);
   const int np = seq - extra;
+  if ((D & 3) == 0) {          // 16-B fp32 loads, 8-B bf16 stores (an HBM-bound pass over g: 232 MB at the headline shape)
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int b = b_lo; b < b_hi; ++b) {
+        const f32x4 v = *(const f32x4*)(g + ((size_t)b * seq + t) * D + c);
+        s += v;
+        if (t >= extra) {
+          const unsigned lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(dyp + ((size_t)b * np + (t - extra)) * D + c) = u32x2{lo, hi};
+          sb += f32x4{bf16lo(lo), bf16hi(lo), bf16lo(hi), bf16hi(hi)};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t < extra) atomicAdd(dextra + (size_t)t * D + c + j, s[j]);
+        else {
+          atomicAdd(dpos + (size_t)(t - extra) * D + c + j, s[j]);
+          atomicAdd(dbias_rows + (size_t)(t - extra) * D + c + j, sb[j]);
+        }
+      }
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < D; c += 256) {
     float s = 0.f, sb = 0.f;
     for (int b = b_lo; b < b_hi; ++b) {
@@ -225,12 +249,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   }
 }
 
+// dbias[c] += sum_r rows[r][c]: 64 columns per workgroup, four row groups summed in parallel and folded through LDS (fixed order)
 __global__ __launch_bounds__(256) void embed_bias_reduce_kernel(const float* __restrict__ rows, float* __restrict__ dbias, int np, int D) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= D) return;
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float s = 0.f;
-  for (int r = 0; r < np; ++r) s += rows[(size_t)r * D + c];
-  dbias[c] += s;
+  if (c < D) {
+#pragma unroll 8
+    for (int r = ty; r < np; r += 4) s += rows[(size_t)r * D + c];
+  }
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < D) dbias[c] += (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
 }
 
 // idx[m] = argmin_k || x[m,:] - e[k,:] ||^2 (first minimum), fp32; the nearest-code search of the
@@ -423,6 +454,6 @@ extern "C" int vitamd_embed_bwd(const float* g, float* dpos, float* dextra, void
   const int bchunk = 32;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(seq, (B + bchunk - 1) / bchunk), dim3(256), 0, (hipStream_t)stream, g, dpos, dextra, (__bf16*)dyp_bf16, dbias_rows, B, seq, extra, D, bchunk);
   if (seq > extra)
-    hipLaunchKernelGGL(embed_bias_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dbias_rows, dbias, seq - extra, D);
+    hipLaunchKernelGGL(embed_bias_reduce_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, dbias_rows, dbias, seq - extra, D);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
