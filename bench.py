@@ -88,6 +88,11 @@ def kernel_roofline(dev):
 
     nt = family(nt_calls, "gemm_nt_pp_kernel")
     tn = family(tn_calls, "gemm_tn_pp_kernel")
+    # (informational) the same weight-gradient GEMMs cut for the whole chip (252 workgroups) instead of the ~128 the step uses so that
+    # they leave half the CUs to the main stream's kernels
+    full = [(n, (lambda l=l, r=r, o=o: ops.gemm_tn(l, r, o, accumulate=False, splits=0)), f) for (n, _, f), (l, r, o) in
+            zip(tn_calls, ((x1, x4, dW2), (x4, x1, dW1), (x3, x1, dWqkv)))]
+    tn["whole_chip_split_per_shape_tflops"] = {name: round(flops / _timed([fn], 10) / 1e9, 1) for name, fn, flops in full}
     out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel (320x256x64 / 256x256x64 ping-pong tiles; the 6 NT GEMM launches of one layer)",
            "achieved": nt["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": nt["frac"],
            "traffic": (nt["traffic"] or {}).get("bytes_per_launch"), "traffic_detail": nt["traffic"], "mfma_util": nt["mfma_util"],
