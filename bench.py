@@ -215,6 +215,13 @@ def main():
     dev = torch.device("cuda", local % ndev)       # (a rehearsal on a 1-GPU box may run several ranks on one card)
     torch.cuda.set_device(dev)
     if world > 1:
+        # The step uses two HIP streams (input-gradient chain / weight-gradient GEMMs) and RCCL brings its own.  HIP multiplexes streams
+        # onto 4 hardware queues in order of first use; two streams on one queue are serialised with barrier packets.  Measured on one
+        # MI355X (tools/ddp_bisect.py): with RCCL initialised BEFORE the side stream's first use the side stream shared the main stream's
+        # queue - 35.5 instead of 31.4 ms/step on every rank.  So the side stream runs its first kernel here, before RCCL exists.
+        # (GPU_MAX_HW_QUEUES=8 cures it too, but hangs two ranks that share one GPU - the gloo rehearsal - so it is not set here.)
+        from vitamd import functions as _F
+        _F.claim_streams(dev)
         backend = os.environ.get("VITAMD_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for rehearsals
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

@@ -17,10 +17,10 @@ def timed(n=5):
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 for _ in range(3): step()
-cfgs = [0, 144, 160, 180, 200, 216, 256]
+cfgs = [int(a) for a in sys.argv[1:]] or [72, 108, 128, 144, 180, 216, 252]
 res = {k: [] for k in cfgs}
 for r in range(4):
     for k in cfgs:
         F.TN_TARGET_WGS = k; res[k].append(timed())
-F.TN_TARGET_WGS = 180
+F.TN_TARGET_WGS = 128
 for k in cfgs: print("target workgroups=%s median %.2f ms/step  %s" % (k, statistics.median(res[k]), ["%.2f" % v for v in res[k]]))

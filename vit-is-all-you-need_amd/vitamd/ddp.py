@@ -15,6 +15,7 @@ enough that the last bucket's latency after backward ends is < 1 ms.
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -113,6 +114,13 @@ class DataParallel(torch.nn.Module):
         from . import functions
         if self._stack_layers:
             functions.GradSink.register(self)
+            dev0 = next(iter(self._stack_layers.values()))[0].flat.device
+            if (self.world > 1 and dist.get_backend(process_group) == "nccl" and dev0 not in functions.SIDE._streams
+                    and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8):
+                import warnings
+                warnings.warn("vitamd.ddp: RCCL was initialised before the weight-gradient side stream was first used; the two HIP "
+                              "streams of the backward pass may share a hardware queue (measured +13 % step time).  Call "
+                              "vitamd.functions.claim_streams(device) before init_process_group (or, one process per GPU, export GPU_MAX_HW_QUEUES=8).")
         # the broadcast above wrote parameters through .data (no version bump): drop every cached bf16 weight copy
         functions.WEIGHTS.clear()
         self._slot = {}

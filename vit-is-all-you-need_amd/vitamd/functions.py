@@ -191,6 +191,18 @@ class _Side:
 SIDE = _Side()
 
 
+def claim_streams(device):
+    """Create the side stream and run a first (empty) kernel on it.  Call this BEFORE torch.distributed.init_process_group("nccl")
+    in a multi-GPU job: HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in order of first use, and with
+    RCCL's streams created first the side stream was measured to land on the main stream's queue - the two are then serialised
+    with barrier packets, 35.5 instead of 31.4 ms/step on every rank (tools/ddp_bisect.py).  Exporting GPU_MAX_HW_QUEUES=8 before
+    the process touches the GPU has the same effect with one process per GPU (it hung two processes sharing one GPU)."""
+    device = torch.device(device)
+    with torch.cuda.stream(SIDE.stream(device)):
+        torch.zeros(16, device=device).add_(1)
+    torch.cuda.current_stream(device).synchronize()
+
+
 class GradSink:
     """Optional hook for data-parallel training (vitamd/ddp.py registers one per DataParallel wrapper): lets the transformer
     stack's backward write each layer's parameter gradients straight into that layer's all-reduce
