@@ -55,6 +55,21 @@ def test_ddp_single_rank_nccl_matches_plain_model(hip):
         dist.destroy_process_group()
 
 
+def test_side_stream_overlaps_main_stream_with_rccl_up(hip):
+    """Guard for the hardware-queue finding, in a fresh process (the queue a stream gets depends on what ran before
+    it in the process): claim_streams -> init_process_group("nccl") -> kernels on the weight-gradient side stream must still run
+    BESIDE main-stream kernels.  tests/_overlap_probe.py prints the time of two few-workgroup GEMMs on two streams over the time of
+    one: serialised streams give ~2.0."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_overlap_probe.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, probe, "claim"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ratio = float(r.stdout.strip().splitlines()[-1].split()[-1])
+    assert ratio < 1.5, r.stdout
+
+
 def _two_rank_worker(rank, world, port, q):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
