@@ -223,11 +223,6 @@ def main():
         from vitamd import functions as _F
         _F.claim_streams(dev)
         backend = os.environ.get("VITAMD_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for rehearsals
-        # Every RCCL channel is a persistent 256-thread workgroup that holds a CU for the whole collective, and the GEMM kernels of
-        # this path cannot share a CU with it (they take the full register file).  The exchange needs little bandwidth (318 MB per
-        # ~31-ms step against 7 x 153 GB/s of xGMI), so cap the channel count: 16 CUs out of 256 keeps every NT GEMM at its round
-        # count (474 tiles: 2 rounds on 240 CUs as on 256).  NCCL's documented knob for exactly this; the caller's environment wins.
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -275,8 +270,7 @@ def main():
     if world > 1:
         devs = [None] * world
         dist.all_gather_object(devs, dev.index)
-        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": devs,
-                     "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS")}
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": devs}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
