@@ -24,6 +24,7 @@ for side in (False, True):
         for _ in range(3):
             model.zero_grad(set_to_none=True); step(x, y)
     torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+    model.zero_grad(set_to_none=True)
     ref_loss = float(step(x, y)); ref_g = {k: p.grad.clone() for k, p in model.named_parameters()}
     model.zero_grad(set_to_none=True)
     g = torch.cuda.CUDAGraph()
