@@ -1,6 +1,7 @@
 """Helper of test_gpu_ddp.py (run as a fresh process): do the main stream and the weight-gradient side stream run kernels side by
 side once RCCL is up?  argv[1] = "claim": vitamd.functions.claim_streams() before init_process_group (the documented order);
-"late": the side stream is first used after RCCL's streams exist.  Prints `ratio <two streams / one stream>`."""
+"late": the side stream is first used after RCCL's streams exist; "heal": as "late", then vitamd.functions.ensure_side_overlap()
+(what DataParallel does for multi-rank jobs).  Prints `ratio <two streams / one stream>`."""
 import os, socket, sys
 import torch, torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +20,9 @@ R, P, Q = 32768, 512, 512                             # 4 output tiles, one work
 l = torch.randn(R, P, device=dev).to(torch.bfloat16)
 r = torch.randn(R, Q, device=dev).to(torch.bfloat16)
 o1, o2 = torch.empty(P, Q, device=dev), torch.empty(P, Q, device=dev)
+if sys.argv[1] == "heal":
+    F.SIDE.stream(dev)
+    print(f"ensure_side_overlap -> {F.ensure_side_overlap(dev):.3f}")
 side = F.SIDE.stream(dev)
 
 

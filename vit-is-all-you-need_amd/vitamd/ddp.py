@@ -115,12 +115,15 @@ class DataParallel(torch.nn.Module):
         if self._stack_layers:
             functions.GradSink.register(self)
             dev0 = next(iter(self._stack_layers.values()))[0].flat.device
-            if (self.world > 1 and dist.get_backend(process_group) == "nccl" and dev0 not in functions.SIDE._streams
-                    and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8):
-                import warnings
-                warnings.warn("vitamd.ddp: RCCL was initialised before the weight-gradient side stream was first used; the two HIP "
-                              "streams of the backward pass may share a hardware queue (measured +13 % step time).  Call "
-                              "vitamd.functions.claim_streams(device) before init_process_group (or, one process per GPU, export GPU_MAX_HW_QUEUES=8).")
+            if self.world > 1 and dev0.type == "cuda" and functions.SIDE.enabled:
+                # the weight-gradient side stream must not share a hardware queue with the main stream (whichever of RCCL and the
+                # model was set up first decides that: DESIGN.md section 7) - measured here, repaired if necessary
+                self.side_overlap_ratio = functions.ensure_side_overlap(dev0)
+                if self.side_overlap_ratio > 1.5:
+                    import warnings
+                    warnings.warn("vitamd.ddp: the weight-gradient side stream is serialised with the main stream (shared hardware queue, "
+                                  f"two-stream / one-stream time {self.side_overlap_ratio:.2f}); call vitamd.functions.claim_streams(device) "
+                                  "before init_process_group, or (one process per GPU) export GPU_MAX_HW_QUEUES=8")
         # the broadcast above wrote parameters through .data (no version bump): drop every cached bf16 weight copy
         functions.WEIGHTS.clear()
         self._slot = {}

@@ -130,6 +130,55 @@ LN_BWD_XHAT = True        # A/B knob (tools/ab_gelu.py): LayerNorm backward read
 GELU_STORED_GRAD = True   # A/B knob (tools/ab_gelu.py); False = keep the pre-activation and evaluate gelu' in the backward
 
 
+def streams_overlap(device, side=None):
+    """Measure whether kernels on `side` (default: the weight-gradient side stream) run beside kernels on the current stream: time of
+    two few-workgroup GEMMs, one per stream, over the time of one.  ~1.0 = concurrent, ~2.0 = the two streams share a hardware
+    queue and are serialised (see claim_streams)."""
+    device = torch.device(device)
+    side = side if side is not None else SIDE.stream(device)
+    R, P = 16384, 512
+    l = torch.ones(R, P, device=device, dtype=torch.bfloat16)
+    o1, o2 = torch.empty(P, P, device=device), torch.empty(P, P, device=device)
+    cur = torch.cuda.current_stream(device)
+
+    def run(both):
+        cur.synchronize(); side.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(cur)
+        if both:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    ops.gemm_tn(l, l, o2, accumulate=False, splits=1)
+        for _ in range(3):
+            ops.gemm_tn(l, l, o1, accumulate=False, splits=1)
+        if both:
+            cur.wait_stream(side)
+        b.record(cur)
+        b.synchronize()
+        return a.elapsed_time(b)
+
+    run(True)
+    one = min(run(False) for _ in range(2))
+    two = min(run(True) for _ in range(2))
+    return two / max(one, 1e-6)
+
+
+def ensure_side_overlap(device, attempts=6):
+    """Make sure the side stream does not share a hardware queue with the current stream: probe it (streams_overlap) and, if the two
+    are serialised, replace it by fresh streams until one runs concurrently.  DataParallel calls this for multi-rank jobs, so the order
+    in which the caller initialised RCCL and first used the model does not matter.  Returns the final ratio."""
+    device = torch.device(device)
+    ratio = streams_overlap(device)
+    kept = []                          # candidates that collided stay alive until the end, so the next one gets another queue
+    while ratio > 1.5 and attempts > 0:
+        kept.append(SIDE._streams[device])
+        SIDE._streams[device] = torch.cuda.Stream(device=device)
+        ratio = streams_overlap(device)
+        attempts -= 1
+    return ratio
+
+
 def _f32c(t):
     return t.detach().to(F32).contiguous()
 
