@@ -6,7 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 import train_vit as TV
 from vitamd import functions as F
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "libcuthief.so"))
+_so = os.path.join(ROOT, "tools", "probes", "libcuthief.so")
+if not os.path.exists(_so):        # hipcc cross-compiles without a GPU; the .so then travels with the snapshot
+    import subprocess
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(ROOT, "tools", "probes", "cu_thief.hip"), "-o", _so])
+lib = ctypes.CDLL(_so)
 lib.thief_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda")
 torch.manual_seed(0)
