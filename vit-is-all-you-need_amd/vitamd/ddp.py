@@ -118,7 +118,12 @@ class DataParallel(torch.nn.Module):
             if self.world > 1 and dev0.type == "cuda" and functions.SIDE.enabled:
                 # the weight-gradient side stream must not share a hardware queue with the main stream (whichever of RCCL and the
                 # model was set up first decides that: DESIGN.md section 7) - measured here, repaired if necessary
-                self.side_overlap_ratio = functions.ensure_side_overlap(dev0)
+                try:
+                    self.side_overlap_ratio = functions.ensure_side_overlap(dev0)
+                except Exception as e:      # a failed probe must not stop training: the streams stay as they are
+                    import warnings
+                    warnings.warn(f"vitamd.ddp: could not probe the side stream ({type(e).__name__}: {e})")
+                    self.side_overlap_ratio = 0.0
                 if self.side_overlap_ratio > 1.5:
                     import warnings
                     warnings.warn("vitamd.ddp: the weight-gradient side stream is serialised with the main stream (shared hardware queue, "
