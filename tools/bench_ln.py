@@ -15,7 +15,11 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n * 1e3
 cases = {"fwd (6 B/elem)": (lambda: ops.layernorm_fwd(xf), 6), "fwd + add (12 B/elem)": (lambda: ops.layernorm_fwd(xf, addend=add), 12),
-         "bwd on bf16 xhat + residual + bf16 copy (14 B/elem)": (lambda: ops.layernorm_bwd(dy, xf, mean, rstd, g_res=res, want_bf16=True, xhat=y), 14)}
-for name, (fn, bpe) in cases.items():
-    us = statistics.median(t(fn) for _ in range(5))
-    print(f"{name:52s} {us:6.1f} us  {M * D * bpe / us / 1e6:.2f} TB/s")
+         "bwd on bf16 xhat + residual + bf16 copy (14 B/elem)": (lambda: ops.layernorm_bwd(dy, xf, mean, rstd, g_res=res, want_bf16=True, xhat=y), 14),
+         "same + column sums of the bf16 copy": (lambda: ops.layernorm_bwd(dy, xf, mean, rstd, g_res=res, want_bf16=True, xhat=y, colsum=cs), 14)}
+cs = torch.zeros(D, device=dev)
+for _ in range(1):
+    for name, (fn, bpe) in cases.items():
+        us = statistics.median(t(fn) for _ in range(5))
+        print(f"{name:52s} {us:6.1f} us  {M * D * bpe / us / 1e6:.2f} TB/s")
+

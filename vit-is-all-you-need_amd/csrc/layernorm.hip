@@ -183,9 +183,12 @@ __global__ __launch_bounds__(256) void ln_bwd_generic(const __bf16* __restrict__
   }
 }
 
-int grid_for(int M) {
+// One row per wave where nothing is shared between rows (12 608 workgroups at M = 50 432: 4-7 % faster than a 2 048-workgroup grid-stride
+// launch, tools/bench_ln.py); the column-sum form keeps a grid-stride loop - every workgroup ends with D atomics (12 608 of them: 312 us).
+int grid_for(int M, bool colsum = false) {
   int blocks = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  return blocks < 2048 ? blocks : 2048;
+  const int cap = !colsum ? 16384 : 1024;           // column-sum form: 2048 -> 118 us, 1024 -> 111, 512 -> 110, 4096 -> 135
+  return blocks < cap ? blocks : cap;
 }
 
 }  // namespace
@@ -223,7 +226,7 @@ static int ln_bwd_launch(const void* dy_bf16, const float* x, const float* mean,
   const unsigned slo = (unsigned)seed, shi = (unsigned)(seed >> 32);
   const __bf16* dy = (const __bf16*)dy_bf16;
   __bf16* gb = (__bf16*)g_bf16;
-  const int grid = grid_for(M);
+  const int grid = grid_for(M, colsum != nullptr && g_bf16 != nullptr);
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(grid), dim3(256), 0, stream, dy, x, mean, rstd, g_res, g_out, gb, colsum, M, dthresh, dscale, slo, shi)
   if (D == 256) { LN_BWD(1); }
   else if (D == 512) { LN_BWD(2); }
@@ -263,7 +266,7 @@ extern "C" int vitamd_layernorm_bwd_xhat(const void* dy_bf16, const void* y_bf16
   const __bf16* dy = (const __bf16*)dy_bf16;
   const float* yx = (const float*)y_bf16;        // the kernel reinterprets it (XH = true)
   __bf16* gb = (__bf16*)g_bf16;
-  const int grid = grid_for(M);
+  const int grid = grid_for(M, colsum != nullptr && g_bf16 != nullptr);
 #define LN_BWDX(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(grid), dim3(256), 0, stream, dy, yx, (const float*)nullptr, rstd, g_res, g_out, gb, colsum, M, dthresh, dscale, slo, shi)
   if (D == 256) { LN_BWDX(1); }
   else if (D == 512) { LN_BWDX(2); }
