@@ -195,24 +195,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_pp_kernel(const GemmTnArgs a,
 #include "experimental/gemm_tn_variants.inc"
 #endif
 
-// out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; one float4 per thread
+// out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; RPT float4 per thread (all loads of a thread are independent: issued together)
+constexpr int RPT = 4;
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int Q, int ldo,
                                                             int tiles_q, int ntile, int splits, int accumulate) {
   const int tile = blockIdx.y;
   const int p0 = (tile / tiles_q) * BP, q0 = (tile % tiles_q) * BQ;
-  const int idx = blockIdx.x * 256 + threadIdx.x;   // float4 index inside the tile: 64 per row
-  const int pl = idx >> 6, ql = (idx & 63) * 4;
-  const int p = p0 + pl, q = q0 + ql;
-  if (p >= P || q >= Q) return;
-  const float* src = ws + (size_t)tile * (BP * BQ) + pl * BQ + ql;
-  f32x4 sum = *(const f32x4*)src;
-  for (int s2 = 1; s2 < splits; ++s2) sum += *(const f32x4*)(src + (size_t)s2 * ntile * (BP * BQ));
-  float* dst = out + (size_t)p * ldo + q;
-  if (q + 3 < Q && (ldo & 3) == 0) {
-    if (accumulate) sum += *(const f32x4*)dst;
-    *(f32x4*)dst = sum;
-  } else {
-    for (int c = 0; c < 4 && q + c < Q; ++c) dst[c] = accumulate ? dst[c] + sum[c] : sum[c];
+  f32x4 sum[RPT];
+  const float* src[RPT];
+  bool ok[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int idx = (blockIdx.x * RPT + k) * 256 + threadIdx.x;   // float4 index inside the tile: 64 per row
+    const int pl = idx >> 6, ql = (idx & 63) * 4;
+    ok[k] = p0 + pl < P && q0 + ql < Q;
+    src[k] = ws + (size_t)tile * (BP * BQ) + pl * BQ + ql;
+    sum[k] = ok[k] ? *(const f32x4*)src[k] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int s2 = 1; s2 < splits; ++s2) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      if (ok[k]) sum[k] += *(const f32x4*)(src[k] + (size_t)s2 * ntile * (BP * BQ));
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    if (!ok[k]) continue;
+    const int idx = (blockIdx.x * RPT + k) * 256 + threadIdx.x;
+    const int p = p0 + (idx >> 6), q = q0 + (idx & 63) * 4;
+    float* dst = out + (size_t)p * ldo + q;
+    if (q + 3 < Q && (ldo & 3) == 0) {
+      if (accumulate) sum[k] += *(const f32x4*)dst;
+      *(f32x4*)dst = sum[k];
+    } else {
+      for (int c = 0; c < 4 && q + c < Q; ++c) dst[c] = accumulate ? dst[c] + sum[k][c] : sum[k][c];
+    }
   }
 }
 
@@ -263,7 +279,7 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
         if (int e = set_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a, tiles_p, tiles_q, splits);
       }
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits, a.accumulate);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits, a.accumulate);
       return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
     }
   }
@@ -271,7 +287,7 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   if (use_ws) {
     if (int e = set_lds(gemm_tn_pp_kernel<true, 8, 4>, lds)) return e;
     hipLaunchKernelGGL((gemm_tn_pp_kernel<true, 8, 4>), grid, block, lds, stream, a, tiles_p, tiles_q, splits);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits,
                        a.accumulate);
   } else {
     if (int e = set_lds(gemm_tn_pp_kernel<false, 8, 4>, lds)) return e;
