@@ -195,8 +195,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_pp_kernel(const GemmTnArgs a,
 #include "experimental/gemm_tn_variants.inc"
 #endif
 
-// out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; RPT float4 per thread (all loads of a thread are independent: issued together)
-constexpr int RPT = 4;
+// out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; RPT float4 per thread
+constexpr int RPT = 1;      // 4 is faster back to back (9.2 vs ~12 us) but slower inside the step (13.9 vs 12.0 us)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int Q, int ldo,
                                                             int tiles_q, int ntile, int splits, int accumulate) {
   const int tile = blockIdx.y;
