@@ -9,7 +9,7 @@ extern "C" int vitamd_abi_version(void) { return 5; }
 int g_vitamd_debug = 0;
 // Diagnostics knob of the EXPERIMENTAL library only (libvitamd_exp.so: tools/ab_*.py, tools/ablate_*.py); process-global, not in the
 // public header, absent from the production library.  Bits marked (!) make results wrong (timing only).
-//   NT GEMM : 2 every tile stores to the same rows(!)   3 plain (temporal) output stores   4 tail split for every GEMM   7 no fc2-forward
+//   NT GEMM : 5 no persistent launches (one workgroup per tile everywhere)   2 every tile stores to the same rows(!)   3 plain (temporal) output stores   4 tail split for every GEMM   7 no fc2-forward
 //             tail split   16 no output stores(!)   18 every tile loads L2-resident panels(!)   19 no 320-row tiles   29 pipe kernel staged
 //             through VGPRs   30 the round-1 pipe kernel instead of the ping-pong kernel
 //   TN GEMM : 6 round-1 16x16x32 form   25 256x384-tile kernel   26-28: 1-3 round-1 timing ablations(!), 5 round-1 LDS-DMA, 6 round-1 VGPR-staged, 7 ping-pong D = 6
