@@ -15,8 +15,8 @@ def timed(n=5):
     step(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-cfgs = {"p0_wgs180": (0, 180, True), "p0_wgs144": (0, 144, True), "p0_wgs128": (0, 128, True), "p0_wgs108": (0, 108, True), "p0_wgs96": (0, 96, True),
-        "p0_wgs72": (0, 72, True), "p1_wgs96": (1, 96, True), "p1_wgs72": (1, 72, True)}
+cfgs = {"policy0_wgs252": (0, 252, True), "policy1_wgs252": (1, 252, True), "policy2_wgs252": (2, 252, True), "policy0_wgs192": (0, 192, True),
+        "no side stream": (0, 252, False)}
 for _ in range(3): step()
 res = {k: [] for k in cfgs}
 for r in range(5):

@@ -308,7 +308,7 @@ int launch_pp(const GemmNtArgs& p, hipStream_t stream) {
   auto kern = gemm_nt_pp_kernel<EPI, MT, LA, LB, PERS>;
   if (int e = set_lds(kern, lds)) return e;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
-  const int cus = PERS ? device_cus() : tiles;
+  const int cus = PERS ? device_cus() - 16 * ((VITAMD_DBG(p) >> 25) & 7) : tiles;     // (dbg bits 25-27 of experimental builds: 16 k fewer persistent workgroups than CUs)
   hipLaunchKernelGGL(kern, dim3(PERS && tiles > cus ? cus : tiles), dim3(512), lds, stream, p);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
 }
