@@ -42,7 +42,10 @@ int vitamd_abi_version(void);
 #define VITAMD_EPI_DMUL 7      /* as DGELU, but aux_bf16 already holds gelu'(pre) (written by GELU_DG): out = bf16(bf16(acc) * aux) */
 
 /* Requirements: K % 64 == 0, N % 4 == 0, ldo % 4 == 0.  bias may be NULL.  `tile`: 0 = auto; 128 = the 128x128 small-problem
- * kernel; 256 / 320 = the ping-pong kernel on 256- / 320-row tiles (320: bias, GELU, residual and dGELU epilogues only).
+ * kernel; 256 / 320 = the ping-pong kernel on 256- / 320-row tiles (320: bias, GELU, residual and dGELU epilogues only),
+ * one workgroup per tile.  Auto launches problems with more tiles than CUs PERSISTENT (one workgroup per CU walking a strided tile
+ * list: faster next to a second stream's kernels, but sensitive to CUs held by other long-running kernels, e.g. collectives);
+ * 512 = auto without persistent launches.
  * Forward of nn.Linear (x W^T + b): A = x, B = W.  Input gradient (dy W): A = dy, B = W^T. */
 int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
                         float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,

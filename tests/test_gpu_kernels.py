@@ -47,6 +47,36 @@ def test_gemm_nt_exact_integers(hip, M, N, K, tile):
     assert torch.equal(out.cpu(), ref)
 
 
+def test_gemm_nt_persistent_launch_equals_one_workgroup_per_tile(hip):
+    """The automatic launch of a problem with more tiles than CUs is persistent (one workgroup per CU walks a strided tile list);
+    tile code 512 is the same automatic choice with one workgroup per tile.  Same kernel, same arithmetic: bit-identical outputs,
+    for every fused epilogue of the training step, with a ragged last tile row."""
+    from vitamd import ops
+    M, D = 320 * 300 + 77, 768          # 301 x 3 = 903 tiles of 320 rows (or 1 128 of 256): more than any CU count
+    a = r16(randn((M, D), 71)).to(dev(), BF16)
+    w = r16(randn((3 * D, D), 72, 0.05)).to(dev(), BF16)
+    wt = r16(randn((D, 3 * D), 73, 0.05)).to(dev(), BF16)
+    a3 = r16(randn((M, 3 * D), 74)).to(dev(), BF16)
+    bias3, bias1 = randn((3 * D,), 75).to(dev()), randn((D,), 76).to(dev())
+    res = randn((M, D), 77).to(dev())
+    cases = [
+        (a, w, ops.EPI_BIAS_BF16, dict(bias=bias3)),
+        (a, w, ops.EPI_GELU_DG, dict(bias=bias3)),
+        (a3, wt, ops.EPI_RESID_F32, dict(bias=bias1, aux=res)),
+        (a3, wt, ops.EPI_BIAS_BF16, dict()),
+        (a, w, ops.EPI_DMUL, dict(aux=a3)),
+    ]
+    for x, wgt, epi, kw in cases:
+        cs1 = torch.zeros(wgt.shape[0], device=dev()) if epi == ops.EPI_DMUL else None
+        cs2 = torch.zeros(wgt.shape[0], device=dev()) if epi == ops.EPI_DMUL else None
+        y1 = ops.gemm_nt(x, wgt, epi, tile=0, colsum=cs1, **kw)
+        y2 = ops.gemm_nt(x, wgt, epi, tile=512, colsum=cs2, **kw)
+        for u, v in zip(y1 if isinstance(y1, tuple) else (y1,), y2 if isinstance(y2, tuple) else (y2,)):
+            assert torch.equal(u, v), epi
+        if cs1 is not None:
+            assert O.rel_l2(cs1.cpu(), cs2.cpu()) < 1e-5          # column sums are accumulated with atomics: order differs
+
+
 @pytest.mark.parametrize("tile", [128, 256, 320])      # the small-problem kernel and the ping-pong kernel on 256- / 320-row tiles
 def test_gemm_nt_epilogues(hip, tile):
     import functools

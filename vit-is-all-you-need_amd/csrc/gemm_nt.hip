@@ -349,7 +349,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   const bool pp_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0;
   constexpr bool tall_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU;
 #ifdef VITAMD_EXPERIMENTAL
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 320) {
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) {
     const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
     if (r != -1) return r;
     if (tile == 7) tile = 256;
@@ -362,7 +362,8 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   // results).  Alone it is as fast as one workgroup per tile; inside the training step, next to the weight-gradient GEMMs of the
   // second stream, it is faster: -0.45 / -0.04 / -0.34 / -0.45 ms per step on four boxes (tools/ab_persistent.py).  The explicit
   // tile codes 256 / 320 keep the one-workgroup-per-tile launch.  (dbg bit 5 of experimental builds: no persistent launches)
-  if (tile == 0 && p.N >= 256 && big_tiles >= 192 && pp_ok && !(VITAMD_DBG(p) & 0x20)) {
+  if (tile == 512) tile = 0;      // ABI code 512: the automatic choice WITHOUT persistent launches (one workgroup per tile)
+  else if (tile == 0 && p.N >= 256 && big_tiles >= 192 && pp_ok && !(VITAMD_DBG(p) & 0x20)) {
     if constexpr (tall_epi) {
       if (prefer_tall(p)) return launch_pp<EPI, 10, 4, 6, true>(p, stream);
     }
@@ -398,7 +399,7 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   // One big-tile workgroup per CU means a launch runs in whole rounds of 256 tiles; a last round that is mostly empty idles most of
   // the chip for a full tile time.  Two remedies live here: the tile height (prefer_tall) and the tail split below.
   constexpr int CUS = 256;
-  const bool tall = p.tile == 0 && prefer_tall(p);
+  const bool tall = (p.tile == 0 || p.tile == 512) && prefer_tall(p);
   const int bm = tall ? 320 : 256;
   const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + 255) / 256;
   const long big_tiles = (long)tiles_m * tiles_n;
@@ -409,13 +410,13 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   // of the side stream already fill the backward tails, +0.2 ms on fc1+GELU at 7.4 rounds of 320-row tiles (the 128x128 kernel's
   // direct-store GELU epilogue costs more than the 0.6 idle round).  Experimental builds: vitamd_set_debug bit 7 turns it off, bit 4 forces it.
   const bool split_on = (VITAMD_DBG(p) & 16) != 0 || (!(VITAMD_DBG(p) & 128) && p.epi == EPI_RESID_F32 && !tall);
-  if (p.tile == 0 && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
+  if ((p.tile == 0 || p.tile == 512) && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
     const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
     const int rows_a = panels_a * bm;
     if (panels_a > 0 && rows_a < p.M) {
       GemmNtArgs a = p, b = p;
       a.M = rows_a;
-      a.tile = tall ? 0 : 256;                                        // (auto picks the 320-row form again for the head part)
+      a.tile = tall ? p.tile : 256;                                   // (auto picks the 320-row form again for the head part)
       const size_t esz_out = (p.epi == EPI_RESID_F32 || p.epi == EPI_F32) ? 4 : 2;
       b.M = p.M - rows_a;
       b.A = (const char*)p.A + (size_t)rows_a * p.K * 2;

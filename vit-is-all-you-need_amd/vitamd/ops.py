@@ -10,6 +10,12 @@ import torch
 from . import lib as _lib
 
 EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32, EPI_GELU_DG, EPI_DMUL = range(8)
+# Large NT GEMMs are launched persistent by default (one workgroup per CU: -0.3 ms/step inside the training step and the reason the
+# weight-gradient stream can use the whole chip).  A persistent workgroup whose CU is held by another
+# long-running kernel starts late with its whole tile list still to do, so the form is sensitive to resident foreign kernels
+# (DESIGN.md section 7); VITAMD_NT_PERSISTENT=0 (or ops.NT_PERSISTENT = False) selects one workgroup per tile instead.
+import os as _os
+NT_PERSISTENT = _os.environ.get("VITAMD_NT_PERSISTENT", "1") != "0"
 LN_EPS = 1e-5
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -55,6 +61,8 @@ def gemm_nt(a, b, epi, *, bias=None, aux=None, out=None, out2=None, colsum=None,
         out2 = torch.empty((M, N), dtype=BF16, device=a.device)
     if bias is not None:
         _need(bias, F32, "bias", 1)
+    if tile == 0 and not NT_PERSISTENT:
+        tile = 512                      # automatic tile choice, one workgroup per tile
     code = _L().vitamd_gemm_nt_bf16(_p(a), _p(b), _p(out), _p(out2), _p(bias), _p(aux), _p(colsum), M, N, K, N, epi,
                                     n_patches, seq, extra, tile, _stream())
     _lib.check(code, f"gemm_nt[M={M},N={N},K={K},epi={epi}]")
