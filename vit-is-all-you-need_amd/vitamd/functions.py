@@ -110,7 +110,7 @@ WEIGHTS = WeightCache()
 
 
 ATTN_FUSED_RESID = False  # A/B knob: x1 = x0 + attention written by the attention forward kernel (N <= 256): correct, measured EQUAL (34.47 vs 34.43 ms)
-TN_TARGET_WGS = 252       # workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU).  Whole-step A/B (tools/ab_splits.py) with the PERSISTENT NT launches: 96 -> 31.21 ms, 128 -> 30.86, 160 -> 30.79, 192 -> 30.55, 216 -> 30.44, 252 -> 30.3, 288 -> 31.0, 504 -> 31.8 (with one NT workgroup per tile the optimum was 128-144: 31.45 vs 32.26 at 252)
+TN_TARGET_WGS = 252 if ops.NT_PERSISTENT else 128   # workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU).  Whole-step A/B (tools/ab_splits.py) with the PERSISTENT NT launches: 96 -> 31.21 ms, 128 -> 30.86, 160 -> 30.79, 192 -> 30.55, 216 -> 30.44, 252 -> 30.3, 288 -> 31.0, 504 -> 31.8 (with one NT workgroup per tile the optimum was 128-144: 31.45 vs 32.26 at 252)
 
 
 def _tn_splits(dW):
