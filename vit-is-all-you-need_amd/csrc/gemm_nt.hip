@@ -338,6 +338,32 @@ static bool prefer_tall(const GemmNtArgs& p) {
 
 #ifdef VITAMD_EXPERIMENTAL
 #include "experimental/gemm_nt_variants.inc"
+#include "gemm_nt_stream.h"
+// tile codes 30-37 (experimental builds): the stream kernel (gemm_nt_stream.h).  30/31/32: MT = 8/6/10 without store slots (30 must equal
+// the persistent ping-pong kernel bit for bit); 33/34/35: the same with one store slot per phase carrying dummy stores of the previous
+// tile's output (timing only; dbg bits 8-15 = live stores per wave and tile, bit 24 = accumulator-layout addresses, bit 16 = no epilogue stores)
+template <int EPI>
+int dispatch_stream(const GemmNtArgs& p, hipStream_t stream, int tile) {
+  if (!((size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0)) return VITAMD_ERR_SHAPE;
+  const StreamTrickle tr{(VITAMD_DBG(p) >> 8) & 0xff, (VITAMD_DBG(p) >> 24) & 1, (VITAMD_DBG(p) >> 26) & 3, (VITAMD_DBG(p) >> 25) & 1};
+  const int cus = device_cus();
+  if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU) {
+    switch (tile) {
+      case 30: return launch_stream<EPI, 8, 2, 0>(p, stream, tr, cus);
+      case 31: return launch_stream<EPI, 6, 3, 0>(p, stream, tr, cus);
+      case 32: return launch_stream<EPI, 10, 2, 0>(p, stream, tr, cus);
+      case 33: return launch_stream<EPI, 8, 2, 1>(p, stream, tr, cus);
+      case 34: return launch_stream<EPI, 6, 3, 1>(p, stream, tr, cus);
+      case 35: return launch_stream<EPI, 10, 2, 1>(p, stream, tr, cus);
+      case 36: return launch_stream<EPI, 8, 2, 0, true>(p, stream, tr, cus);     // split roles: row 0 loads, row 1 stores
+      case 37: return launch_stream<EPI, 6, 3, 0, true>(p, stream, tr, cus);
+      case 38: return launch_stream<EPI, 8, 2, 1, false, 0, 4>(p, stream, tr, cus);     // store slot behind the 4th / 8th / 12th MFMA of the matrix section
+      case 39: return launch_stream<EPI, 8, 2, 1, false, 0, 8>(p, stream, tr, cus);
+      case 40: return launch_stream<EPI, 8, 2, 1, false, 0, 12>(p, stream, tr, cus);
+    }
+  }
+  return VITAMD_ERR_ARG;
+}
 #endif
 
 template <int EPI>
@@ -349,6 +375,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   const bool pp_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0;
   constexpr bool tall_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU;
 #ifdef VITAMD_EXPERIMENTAL
+  if (tile >= 30 && tile <= 40) return dispatch_stream<EPI>(p, stream, tile);
   if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) {
     const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
     if (r != -1) return r;
