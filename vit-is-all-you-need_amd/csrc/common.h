@@ -85,6 +85,29 @@ __device__ __forceinline__ void asm_glds16(srd_t srd, unsigned lds_dst, unsigned
                : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
+// 4 B per lane from srd[voff + soff] to LDS byte address lds_dst (wave-uniform) + 4*lane: one row of 64 floats per wave-instruction
+__device__ __forceinline__ void asm_glds4(srd_t srd, unsigned lds_dst, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
+// 16 B per lane from srd[voff] into registers, from inline asm (invisible to hipcc's wait bookkeeping, like asm_glds16): the caller waits with a
+// counted s_waitcnt statement that names the destination as a "+v" operand before the first use (cdna_hip_programming.md section 5.7, form ii).
+// Out-of-range offsets return zeros.
+__device__ __forceinline__ u32x4 asm_bload16(srd_t srd, unsigned voff, unsigned soff = 0u) {
+  u32x4 r;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+  return r;
+}
+
+// 16 B per lane to srd[voff + soff], non-temporal, from inline asm.  The s_nop 1 inside the statement is the store-data hazard pad (the next
+// instruction may overwrite the data registers; cdna_hip_programming.md section 5.7 item 1): with a REGISTER soffset hipcc does not pad its
+// own buffer stores either, and on gfx950 such a store was seen sending the next row's index in place of a data dword.
+__device__ __forceinline__ void asm_bstore16_nt(u32x4 data, srd_t srd, unsigned voff, unsigned soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" :: "v"(data), "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
 // dynamic-LDS opt-in for a kernel; called on every launch (a cheap host call) so it holds for whichever device is current
 template <typename K>
 static inline int set_lds(K kern, int bytes) {

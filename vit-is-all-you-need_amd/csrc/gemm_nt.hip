@@ -336,31 +336,17 @@ static bool prefer_tall(const GemmNtArgs& p) {
   return r320 * 320 <= r256 * 256;     // ties go to the tall tile: 142 instead of 128 FLOP per staged byte (whole-step A/B: -0.5 ms on the N = 3072 GEMMs alone)
 }
 
+#include "gemm_nt_seam.h"
+
 #ifdef VITAMD_EXPERIMENTAL
 #include "experimental/gemm_nt_variants.inc"
-#include "gemm_nt_stream.h"
-// tile codes 30-37 (experimental builds): the stream kernel (gemm_nt_stream.h).  30/31/32: MT = 8/6/10 without store slots (30 must equal
-// the persistent ping-pong kernel bit for bit); 33/34/35: the same with one store slot per phase carrying dummy stores of the previous
-// tile's output (timing only; dbg bits 8-15 = live stores per wave and tile, bit 24 = accumulator-layout addresses, bit 16 = no epilogue stores)
+// tile codes 24 / 25 (experimental builds): the seam kernel (gemm_nt_seam.h) on 256- / 320-row tiles whatever the automatic rule says
 template <int EPI>
-int dispatch_stream(const GemmNtArgs& p, hipStream_t stream, int tile) {
-  if (!((size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0)) return VITAMD_ERR_SHAPE;
-  const StreamTrickle tr{(VITAMD_DBG(p) >> 8) & 0xff, (VITAMD_DBG(p) >> 24) & 1, (VITAMD_DBG(p) >> 26) & 3, (VITAMD_DBG(p) >> 25) & 1};
-  const int cus = device_cus();
-  if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU) {
-    switch (tile) {
-      case 30: return launch_stream<EPI, 8, 2, 0>(p, stream, tr, cus);
-      case 31: return launch_stream<EPI, 6, 3, 0>(p, stream, tr, cus);
-      case 32: return launch_stream<EPI, 10, 2, 0>(p, stream, tr, cus);
-      case 33: return launch_stream<EPI, 8, 2, 1>(p, stream, tr, cus);
-      case 34: return launch_stream<EPI, 6, 3, 1>(p, stream, tr, cus);
-      case 35: return launch_stream<EPI, 10, 2, 1>(p, stream, tr, cus);
-      case 36: return launch_stream<EPI, 8, 2, 0, true>(p, stream, tr, cus);     // split roles: row 0 loads, row 1 stores
-      case 37: return launch_stream<EPI, 6, 3, 0, true>(p, stream, tr, cus);
-      case 38: return launch_stream<EPI, 8, 2, 1, false, 0, 4>(p, stream, tr, cus);     // store slot behind the 4th / 8th / 12th MFMA of the matrix section
-      case 39: return launch_stream<EPI, 8, 2, 1, false, 0, 8>(p, stream, tr, cus);
-      case 40: return launch_stream<EPI, 8, 2, 1, false, 0, 12>(p, stream, tr, cus);
-    }
+int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
+  if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
+    if (!seam_ok(p)) return VITAMD_ERR_SHAPE;
+    if (tile == 24) return launch_seam<EPI, 8>(p, stream, device_cus());
+    if constexpr (EPI != EPI_DGELU) return launch_seam<EPI, 10>(p, stream, device_cus());
   }
   return VITAMD_ERR_ARG;
 }
@@ -375,7 +361,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   const bool pp_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0;
   constexpr bool tall_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU;
 #ifdef VITAMD_EXPERIMENTAL
-  if (tile >= 30 && tile <= 40) return dispatch_stream<EPI>(p, stream, tile);
+  if (tile == 24 || tile == 25) return dispatch_seam_explicit<EPI>(p, stream, tile);
   if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) {
     const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
     if (r != -1) return r;
@@ -391,6 +377,19 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   // tile codes 256 / 320 keep the one-workgroup-per-tile launch.  (dbg bit 5 of experimental builds: no persistent launches)
   if (tile == 512) tile = 0;      // ABI code 512: the automatic choice WITHOUT persistent launches (one workgroup per tile)
   else if (tile == 0 && p.N >= 256 && big_tiles >= 192 && pp_ok && !(VITAMD_DBG(p) & 0x20)) {
+    // Short K loops with several tiles per CU: the SEAM form of the persistent kernel (gemm_nt_seam.h: the next tile's pipeline fill is requested
+    // before the epilogue, the epilogue runs beside the operand buffers).  Measured on the ViT-B launches (tools/bench_seam.py): QKV 172 -> 163 us,
+    // fc1+GELU 316 -> 298, dgrad-fc2 298 -> 268 (K = 768, 7-10 tiles per CU); equal or 4 % slower where a CU sees only two tiles of a long K loop
+    // (dgrad-fc1 K = 3072, dgrad-QKV K = 2304), which therefore stay on the form below.  Bit-identical results.  (dbg bit 17: off)
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
+      if (seam_ok(p) && p.K <= 1536 && !(VITAMD_DBG(p) & 0x20000)) {
+        const int cus = device_cus();
+        if constexpr (EPI != EPI_DGELU) {
+          if (prefer_tall(p) && (long)((p.M + 319) / 320) * ((p.N + 255) / 256) >= 3L * cus) return launch_seam<EPI, 10>(p, stream, cus);
+        }
+        if (big_tiles >= 3L * cus) return launch_seam<EPI, 8>(p, stream, cus);
+      }
+    }
     if constexpr (tall_epi) {
       if (prefer_tall(p)) return launch_pp<EPI, 10, 4, 6, true>(p, stream);
     }
@@ -425,7 +424,7 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
   // One big-tile workgroup per CU means a launch runs in whole rounds of 256 tiles; a last round that is mostly empty idles most of
   // the chip for a full tile time.  Two remedies live here: the tile height (prefer_tall) and the tail split below.
-  constexpr int CUS = 256;
+  const int CUS = device_cus();
   const bool tall = (p.tile == 0 || p.tile == 512) && prefer_tall(p);
   const int bm = tall ? 320 : 256;
   const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + 255) / 256;
