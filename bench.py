@@ -79,45 +79,67 @@ def kernel_roofline(dev):
 
     def family(calls, kernel):
         # per shape (informational): ten launches back to back; reported: the launches in layer order, eight layers' worth between one pair of events
-        detail = {name: round(flops / _timed([fn], 10) / 1e9, 1) for name, fn, flops in calls}
+        detail = {name: round(flops / sorted(_timed([fn], 5) for _ in range(3))[1] / 1e9, 1) for name, fn, flops in calls}     # median of three 5-launch timings
         ms = _timed([fn for _, fn, _ in calls], 8)
         ach = sum(f for _, _, f in calls) / ms / 1e9
         return {"kernel": kernel, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "launches_per_layer": len(calls), "avg_launch_us": round(ms * 1e3 / len(calls), 1), "per_shape_tflops": detail,
-                "mfma_util": (prof.get("mfma_util") or {}).get(kernel), "traffic": (prof.get("traffic") or {}).get(kernel)}
+                "recorded_mfma_util": (prof.get("mfma_util") or {}).get(kernel), "recorded_traffic": (prof.get("traffic") or {}).get(kernel)}
 
-    nt = family(nt_calls, "gemm_nt_pp_kernel")
+    nt = family(nt_calls, "gemm_nt")          # gemm_nt_pp_kernel and its seam form gemm_nt_seam_kernel
     tn = family(tn_calls, "gemm_tn_pp_kernel")
     # (informational) the same weight-gradient GEMMs cut for the whole chip (252 workgroups) instead of the ~128 the step uses so that
     # they leave half the CUs to the main stream's kernels
     full = [(n, (lambda l=l, r=r, o=o: ops.gemm_tn(l, r, o, accumulate=False, splits=0)), f) for (n, _, f), (l, r, o) in
             zip(tn_calls, ((x1, x4, dW2), (x4, x1, dW1), (x3, x1, dWqkv)))]
     tn["whole_chip_split_per_shape_tflops"] = {name: round(flops / _timed([fn], 10) / 1e9, 1) for name, fn, flops in full}
-    out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel (320x256x64 / 256x256x64 ping-pong tiles; the 6 NT GEMM launches of one layer)",
+    # `achieved` / `per_shape_tflops` are measured live in this run.  `recorded_*` and `traffic` are NOT: they come from rocprofv3 PMC passes of
+    # this same command committed under profiles/ (collected with --pmc in separate runs, as the guide prescribes), and say so: "static": true;
+    # "stale": true when the kernel sources have changed since those passes were made (then `traffic` is null).
+    rec_ok = prof.get("source") is not None and not prof.get("stale")
+    out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel + gemm_nt_seam_kernel (320x256x64 / 256x256x64 ping-pong tiles; the 6 NT GEMM launches of one layer)",
            "achieved": nt["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": nt["frac"],
-           "traffic": (nt["traffic"] or {}).get("bytes_per_launch"), "traffic_detail": nt["traffic"], "mfma_util": nt["mfma_util"],
-           "per_shape_tflops": nt["per_shape_tflops"], "kernels": {"gemm_nt_pp_kernel": nt, "gemm_tn_pp_kernel": tn},
-           "pmc_source": prof.get("source")}
+           "traffic": (nt["recorded_traffic"] or {}).get("bytes_per_launch") if rec_ok else None,
+           "recorded": {"static": True, "stale": bool(prof.get("stale")), "source": prof.get("source"), "made_at": prof.get("meta"),
+                        "traffic_detail": nt["recorded_traffic"], "mfma_util": nt["recorded_mfma_util"]},
+           "per_shape_tflops": nt["per_shape_tflops"], "kernels": {"gemm_nt": nt, "gemm_tn_pp_kernel": tn}}
     return out
 
 
-PMC_DIR = os.path.join("profiles", "r02")
-NT_ALGO_MB = {"<0, 8": 339, "<0, 10": 339, "<1, 10": 702, "<2, 10": 625, "<3, 10": 702}     # algorithmic MB per launch by (EPI, MT) template prefix
+PMC_DIR = os.path.join("profiles", "r03")
+NT_ALGO_MB = (313 + 702 + 625 + 702 + 392 + 313) / 6.0     # algorithmic MB per launch, mean over the six NT launches of a layer
+
+
+def csrc_sha16():
+    """hash of the kernel sources: a recorded PMC profile belongs to exactly one state of them"""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "vit-is-all-you-need_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_profile():
-    """Per-kernel MFMA utilisation and HBM bytes per launch from the committed rocprofv3 PMC passes of this bench command
-    (profiles/r02/final_pmc_mfma.json: tools/pmc_mfma.py; final_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes folded
-    by tools/pmc_traffic.py with the gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE).  Missing files -> empty."""
+    """Per-kernel MFMA utilisation and HBM bytes per launch RECORDED by rocprofv3 PMC passes of this bench command and committed under
+    profiles/ (final_pmc_mfma.json: tools/pmc_mfma.py; final_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes folded by
+    tools/pmc_traffic.py with the gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE; final_pmc_meta.json: the source hash they were made at).
+    Missing files -> empty; a source hash that differs from the tree's -> "stale"."""
     out = {}
+    try:
+        meta = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_meta.json")))
+        out["meta"] = meta
+        out["stale"] = meta.get("csrc_sha16") != csrc_sha16()
+    except Exception:
+        out["stale"] = True
     try:
         mf = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_mfma.json")))
         util = {}
-        for fam in ("gemm_nt_pp_kernel", "gemm_tn_pp_kernel"):
-            rows = [(v["launches"], v["avg_us_profiled"], v["mfma_util"]) for k, v in mf.items() if fam in k and v["avg_us_profiled"] > 50]
+        for fam in ("gemm_nt", "gemm_tn_pp_kernel"):
+            sel = {k: v for k, v in mf.items() if (("gemm_nt_pp_kernel" in k or "gemm_nt_seam_kernel" in k) if fam == "gemm_nt" else fam in k) and v["avg_us_profiled"] > 50}
+            rows = [(v["launches"], v["avg_us_profiled"], v["mfma_util"]) for v in sel.values()]
             if rows:       # time-weighted over the family's launches
                 util[fam] = {"mfma_busy_frac": round(sum(n * t * u for n, t, u in rows) / sum(n * t for n, t, _ in rows), 4),
-                             "per_instantiation": {k.split(fam)[1].split("(")[0]: v["mfma_util"] for k, v in mf.items() if fam in k and v["avg_us_profiled"] > 50}}
+                             "per_instantiation": {k.split("::")[-1].split("(")[0]: v["mfma_util"] for k, v in sel.items()}}
         out["mfma_util"] = util
         out["source"] = os.path.join(PMC_DIR, "final_pmc_mfma.json")
     except Exception:
@@ -125,12 +147,11 @@ def pmc_profile():
     try:
         tr = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_hbm_traffic.json")))
         traffic = {}
-        nt = {k.split("gemm_nt_pp_kernel")[1].split("(")[0]: v for k, v in tr.items() if "gemm_nt_pp_kernel<" in k and v["launches"] >= 12}
+        nt = [v for k, v in tr.items() if ("gemm_nt_pp_kernel<" in k or "gemm_nt_seam_kernel<" in k) and v["launches"] >= 12]
         if nt:
-            tot_n = sum(v["launches"] for v in nt.values())
-            mb = sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in nt.values()) / tot_n
-            algo = sum(v["launches"] * next((a for pre, a in NT_ALGO_MB.items() if k.startswith(pre)), 0) for k, v in nt.items()) / tot_n
-            traffic["gemm_nt_pp_kernel"] = {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int(algo * 1e6)}
+            tot_n = sum(v["launches"] for v in nt)
+            mb = sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in nt) / tot_n
+            traffic["gemm_nt"] = {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int(NT_ALGO_MB * 1e6)}
         tn = [v for k, v in tr.items() if "gemm_tn_pp_kernel<" in k]
         if tn:
             tot_n = sum(v["launches"] for v in tn)
@@ -163,6 +184,20 @@ def cpu_baseline():
     dt = time.time() - t0
     return {"value": round(bs * iters / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{iters} x (batch {bs} ViT-B/16 224 fp32 forward+loss+backward), CPU oracle, {dt:.1f} s"}
+
+
+def gather_dist_info(device_index, own_ms, finish_wait_ms, diagnostics):
+    """What an N > 1 line carries so that a bad scaling number can be diagnosed from the JSON alone: every rank's own step time, the
+    time each rank's main stream spent waiting in finish() for the gradient all-reduces (event-timed, GPU timeline; ~0 = fully
+    hidden under backward), and rank 0's DataParallel diagnostics (side-stream overlap probe, measured NT launch form, buckets).
+    Works on any backend (objects are gathered): tests/_rank_probe.py drives it over gloo."""
+    world = dist.get_world_size()
+    rows = [None] * world
+    dist.all_gather_object(rows, {"device": device_index, "ms": round(float(own_ms), 3), "finish_wait_ms": round(float(finish_wait_ms), 3)})
+    info = {"world_size": world, "backend": dist.get_backend(), "devices": [r["device"] for r in rows],
+            "per_rank_ms": [r["ms"] for r in rows], "finish_wait_ms": [r["finish_wait_ms"] for r in rows]}
+    info.update(diagnostics)
+    return info
 
 
 def free_port():
@@ -212,6 +247,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = max(1, torch.cuda.device_count())
+    if world > ndev and os.environ.get("GPU_MAX_HW_QUEUES"):
+        # several ranks per card AND a raised hardware-queue count: the combination that hung in round 2 (vitamd.ddp.check_hw_queues)
+        sys.exit(f"bench.py: {world} ranks on {ndev} GPU(s) with GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']} set: refusing "
+                 "(oversubscribed hardware queues hang this step; unset the variable or run one rank per GPU)")
     dev = torch.device("cuda", local % ndev)       # (a rehearsal on a 1-GPU box may run several ranks on one card)
     torch.cuda.set_device(dev)
     if world > 1:
@@ -219,7 +258,7 @@ def main():
         # onto 4 hardware queues in order of first use; two streams on one queue are serialised with barrier packets.  Measured on one
         # MI355X (tools/ddp_bisect.py): with RCCL initialised BEFORE the side stream's first use the side stream shared the main stream's
         # queue - 35.5 instead of 31.4 ms/step on every rank.  So the side stream runs its first kernel here, before RCCL exists.
-        # (GPU_MAX_HW_QUEUES=8 cures it too, but hangs two ranks that share one GPU - the gloo rehearsal - so it is not set here.)
+        # (GPU_MAX_HW_QUEUES=8 cures it too with one rank per GPU, but hangs ranks that share a GPU: refused above and in vitamd.ddp.)
         from vitamd import functions as _F
         _F.claim_streams(dev)
         backend = os.environ.get("VITAMD_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for rehearsals
@@ -239,13 +278,21 @@ def main():
     images = torch.randn(PER_GPU_BATCH, 3, 224, 224, generator=g).to(dev)
     labels = torch.randint(0, 1000, (PER_GPU_BATCH,), generator=g).to(dev)
 
-    def step():
+    finish_events = []                       # (before, after) net.finish() on the main stream: how long backward's tail waits for the all-reduces
+
+    def step(timed=False):
         model.zero_grad(set_to_none=True)
         WEIGHTS.clear()                      # weights are re-cast to bf16 every step, as in training
         loss = torch.nn.functional.cross_entropy(net(images), labels)
         loss.backward()
         if world > 1:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             net.finish()
+            if timed:
+                e1.record()
+                finish_events.append((e0, e1))
         return loss
 
     for _ in range(args.warmup):
@@ -255,12 +302,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = step(timed=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_ms = elapsed / args.steps * 1e3
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -268,9 +316,8 @@ def main():
     loss_val = float(loss.item())
     dist_info = {"world_size": 1, "backend": backend, "devices": [dev.index]}
     if world > 1:
-        devs = [None] * world
-        dist.all_gather_object(devs, dev.index)
-        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": devs}
+        wait_ms = sum(a.elapsed_time(b) for a, b in finish_events) / max(1, len(finish_events))
+        dist_info = gather_dist_info(dev.index, own_ms, wait_ms, net.diagnostics())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -44,7 +44,8 @@ int vitamd_abi_version(void);
 /* Requirements: K % 64 == 0, N % 4 == 0, ldo % 4 == 0.  bias may be NULL.  `tile`: 0 = auto; 128 = the 128x128 small-problem
  * kernel; 256 / 320 = the ping-pong kernel on 256- / 320-row tiles (320: bias, GELU, residual and dGELU epilogues only),
  * one workgroup per tile.  Auto launches problems with more tiles than CUs PERSISTENT (one workgroup per CU walking a strided tile
- * list: faster next to a second stream's kernels, but sensitive to CUs held by other long-running kernels, e.g. collectives);
+ * list: faster next to a second stream's kernels, but sensitive to CUs held by other long-running kernels, e.g. collectives; with a
+ * short reduction dim (K <= 1536) and >= 3 tiles per CU in the form that requests the next tile's operands before the epilogue);
  * 512 = auto without persistent launches.
  * Forward of nn.Linear (x W^T + b): A = x, B = W.  Input gradient (dy W): A = dy, B = W^T. */
 int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
@@ -52,9 +53,9 @@ int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, con
                         int tile, void* stream);
 
 /* fc2 with dropout: out f32 = resid + dropout_p(bf16(A.B^T + bias)), mask = hash(seed, row*N+col).
- * replaces transformer.py:39-40,44 (Linear + nn.Dropout(p) + residual add) in training mode. */
+ * replaces transformer.py:39-40,44 (Linear + nn.Dropout(p) + residual add) in training mode.  `tile` as for vitamd_gemm_nt_bf16. */
 int vitamd_linear_dropout_resid_bf16(const void* A, const void* B, float* out, const float* bias, const float* resid,
-                                     int M, int N, int K, float dropout_p, unsigned long long seed, void* stream);
+                                     int M, int N, int K, float dropout_p, unsigned long long seed, int tile, void* stream);
 
 /* Weight gradient: out[P,Q] (fp32) += sum_r L[r,p] * Rm[r,q]   (dW = dY^T X).  Accumulates with
  * fp32 atomics, so `out` must hold the running gradient (zeros for a fresh one).

@@ -172,3 +172,46 @@ def test_ddp_bucket_state_machine_world2():
                 else:
                     assert got is not None and torch.allclose(torch.from_numpy(got), w, rtol=1e-5, atol=1e-6), (r, case)
         assert results[r]["twice"] == "raised", results[r]["twice"]
+
+
+# ---------------------------------------------------------------- run-time launch form and the hardware-queue guard
+def test_select_launch_form_rule():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-is-all-you-need_amd"))
+    from vitamd import ddp
+    assert ddp.select_launch_form(30.3, 31.4) is True          # persistent faster: keep it
+    assert ddp.select_launch_form(35.3, 33.0) is False         # resident collectives hurt the persistent form more: one workgroup per tile
+    assert ddp.select_launch_form(30.00, 29.90) is True        # inside the 1 % margin: a tie keeps the persistent form
+
+
+def test_choose_launch_form_with_stub_timer_sets_runtime_switches():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-is-all-you-need_amd"))
+    from vitamd import ddp, ops, functions
+    keep = ops.NT_PERSISTENT
+    try:
+        seen = []
+        rec = ddp.choose_launch_form("cpu", measure=lambda form: (seen.append((form, ops.NT_PERSISTENT)), 35.3 if form else 33.0)[1])
+        assert seen == [(True, True), (False, False)]            # each form is measured with the switch really set
+        assert rec["chosen"] == "per_tile" and rec["persistent_ms"] == 35.3 and rec["per_tile_ms"] == 33.0 and rec["source"] == "measured"
+        assert ops.NT_PERSISTENT is False and functions.tn_target_wgs() == 128      # the weight-gradient cut follows at run time
+        rec = ddp.choose_launch_form("cpu", measure=lambda form: 30.3 if form else 31.4)
+        assert rec["chosen"] == "persistent" and ops.NT_PERSISTENT is True and functions.tn_target_wgs() == 252
+        functions.TN_TARGET_WGS = 192                                # an explicit value overrides the rule
+        assert functions.tn_target_wgs() == 192
+    finally:
+        ops.NT_PERSISTENT = keep
+        functions.TN_TARGET_WGS = None
+
+
+def test_hw_queue_guard():
+    import sys
+    import pytest
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-is-all-you-need_amd"))
+    from vitamd import ddp
+    shared, apart = [("box", 0), ("box", 0)], [("box", 0), ("box", 1)]
+    ddp.check_hw_queues(shared, environ={})                          # default queue count: fine
+    ddp.check_hw_queues(apart, environ={"GPU_MAX_HW_QUEUES": "8"})   # one rank per GPU: fine
+    ddp.check_hw_queues([None, None], environ={"GPU_MAX_HW_QUEUES": "8"})   # CPU ranks
+    with pytest.raises(ddp.SharedDeviceQueuesError, match="share one GPU"):
+        ddp.check_hw_queues(shared, environ={"GPU_MAX_HW_QUEUES": "8"})

@@ -3,7 +3,7 @@
 #include "vitamd_internal.h"
 #include "../../include/vitamd.h"
 
-extern "C" int vitamd_abi_version(void) { return 5; }
+extern "C" int vitamd_abi_version(void) { return 6; }
 
 #ifdef VITAMD_EXPERIMENTAL
 int g_vitamd_debug = 0;
@@ -55,8 +55,9 @@ static bool dropout_params(float p, unsigned& thresh, float& scale) {
 
 // fc2 with dropout: out f32 = resid + dropout_p(bf16(A.B^T + bias)) — reference transformer.py:39-40,44
 extern "C" int vitamd_linear_dropout_resid_bf16(const void* A, const void* B, float* out, const float* bias, const float* resid,
-                                                int M, int N, int K, float dropout_p, unsigned long long seed, void* stream) {
-  GemmNtArgs p{A, B, out, nullptr, bias, resid, nullptr, M, N, K, N, EPI_RESID_F32, 0, 0, 0, 0, VITAMD_GDBG, 0u, 1.0f,
+                                                int M, int N, int K, float dropout_p, unsigned long long seed, int tile, void* stream) {
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) return VITAMD_ERR_ARG;
+  GemmNtArgs p{A, B, out, nullptr, bias, resid, nullptr, M, N, K, N, EPI_RESID_F32, 0, 0, 0, tile, VITAMD_GDBG, 0u, 1.0f,
                (unsigned)seed, (unsigned)(seed >> 32), 0, 0};
   if (!dropout_params(dropout_p, p.drop_thresh, p.drop_scale)) return VITAMD_ERR_ARG;
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);

@@ -24,6 +24,113 @@ import torch.distributed as dist
 CLEAN, LOCAL, REDUCING = 0, 1, 2
 
 
+class SharedDeviceQueuesError(RuntimeError):
+    pass
+
+
+def ranks_share_device(device_ids):
+    """device_ids: one (host, device index) per rank (None for ranks that are not on a GPU).  True when two ranks sit on the same card."""
+    seen = set()
+    for d in device_ids:
+        if d is None:
+            continue
+        if d in seen:
+            return True
+        seen.add(d)
+    return False
+
+
+def check_hw_queues(device_ids, environ=None):
+    """Refuse GPU_MAX_HW_QUEUES together with several ranks on one card.
+
+    HIP maps every stream of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With ONE process per GPU raising it to 8
+    is harmless (it also keeps the weight-gradient side stream off the main stream's queue).  With TWO processes on one GPU and 8
+    queues each - the rehearsal of the multi-rank path on a one-GPU box - the step hung on both ranks (round 2):
+    each rank then asks for 8 compute queues plus its copy queues, more than the card keeps resident at once, so the scheduler
+    time-slices the queues; this path's cross-stream dependencies are barrier packets that wait, ON the hardware queue, for a signal
+    another queue of the same process must produce, and a waiting queue that holds its hardware slot while the producing queue is
+    swapped out never gets its signal.  With the default 4 queues per process every queue stays resident and the same rehearsal runs.
+    So the combination is an error here, not a warning."""
+    environ = os.environ if environ is None else environ
+    if environ.get("GPU_MAX_HW_QUEUES") and ranks_share_device(device_ids):
+        raise SharedDeviceQueuesError(
+            f"GPU_MAX_HW_QUEUES={environ['GPU_MAX_HW_QUEUES']} is set and several ranks share one GPU: this configuration hung in round 2 "
+            "(oversubscribed hardware queues under cross-stream barrier packets, DESIGN.md section 7).  Unset GPU_MAX_HW_QUEUES "
+            "(the default 4 queues per process work), or run one rank per GPU.")
+
+
+def select_launch_form(persistent_ms, per_tile_ms, margin=0.01):
+    """Pure decision rule of choose_launch_form: persistent NT launches unless one workgroup per tile is faster by more than `margin`
+    (relative): a tie keeps the form that is faster when no collective is resident."""
+    return not (per_tile_ms < persistent_ms * (1.0 - margin))
+
+
+def choose_launch_form(device, group=None, measure=None, rows=16384, width=768, iters=4, bucket_mb=28.3):
+    """Pick the NT GEMM launch form for a multi-rank job FROM A MEASUREMENT on this job's own devices and fabric, and set it
+    (ops.NT_PERSISTENT; functions.tn_target_wgs follows).  A persistent workgroup whose CU is held by a resident communication kernel
+    starts late with its whole tile list still to do (one resident foreign workgroup 30.3 -> 35.3 ms/step in the
+    persistent form, 31.4 -> 33.0 with one workgroup per tile), so which form wins depends on how long the collectives of a step are
+    resident - which only the running job can tell.  Measured here: `iters` x [bucket-sized all-reduce enqueued on the side stream +
+    the six NT launches of one layer at (rows, width)] in each form; every rank takes the MAX over ranks, so all ranks decide alike.
+    `measure(form) -> ms` replaces the GPU measurement in the CPU unit test.  Returns the record kept as DataParallel.launch_form."""
+    from . import ops
+    if measure is None:
+        measure = lambda form: _measure_form(form, torch.device(device), group, rows, width, iters, bucket_mb)   # noqa: E731
+    keep = ops.NT_PERSISTENT
+    times = {}
+    try:
+        for form in (True, False):
+            ops.NT_PERSISTENT = form
+            t = torch.tensor([float(measure(form))], dtype=torch.float64)
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                t = t.to(device) if dist.get_backend(group) == "nccl" else t
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            times[form] = float(t.item())
+    finally:
+        ops.NT_PERSISTENT = keep
+    chosen = select_launch_form(times[True], times[False])
+    ops.NT_PERSISTENT = chosen
+    return {"persistent_ms": round(times[True], 4), "per_tile_ms": round(times[False], 4), "chosen": "persistent" if chosen else "per_tile",
+            "source": "measured"}
+
+
+def _measure_form(form, device, group, rows, width, iters, bucket_mb):
+    """ms per iteration of [all-reduce of one layer bucket on the side stream] beside [the six NT launches of a layer] (the current
+    ops.NT_PERSISTENT decides the launch form)"""
+    from . import ops, functions
+    D = width
+    bf = torch.bfloat16
+    x1, x3, x4 = (torch.randn(rows, n, device=device).to(bf) for n in (D, 3 * D, 4 * D))
+    ws = [torch.randn(n, k, device=device).mul_(0.03).to(bf) for n, k in ((3 * D, D), (4 * D, D), (D, 4 * D), (4 * D, D), (D, 4 * D), (D, 3 * D))]
+    res = torch.randn(rows, D, device=device)
+    cs = torch.zeros(4 * D, device=device)
+    bucket = torch.zeros(int(bucket_mb * (1 << 20) / 4), device=device)
+    side = functions.SIDE.stream(device)
+    main = torch.cuda.current_stream(device)
+
+    def once():
+        ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+        with torch.cuda.stream(side):
+            work = dist.all_reduce(bucket, group=group, async_op=True)
+        ops.gemm_nt(x1, ws[0], ops.EPI_BIAS_BF16)
+        ops.gemm_nt(x1, ws[1], ops.EPI_GELU_DG)
+        ops.gemm_nt(x4, ws[2], ops.EPI_RESID_F32, aux=res)
+        ops.gemm_nt(x1, ws[3], ops.EPI_DMUL, aux=x4, colsum=cs)
+        ops.gemm_nt(x4, ws[4], ops.EPI_BIAS_BF16)
+        ops.gemm_nt(x3, ws[5], ops.EPI_BIAS_BF16)
+        work.wait()
+
+    once()
+    torch.cuda.synchronize(device)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(main)
+    for _ in range(iters):
+        once()
+    b.record(main)
+    b.synchronize()
+    return a.elapsed_time(b) / iters
+
+
 class _Bucket:
     """One flat fp32 all-reduce unit.  state: CLEAN = no gradient of this step yet; LOCAL = holds this rank's (possibly
     accumulated) gradients, not reduced; REDUCING = its all-reduce has been enqueued (nothing may write it before finish())."""
@@ -76,6 +183,15 @@ class DataParallel(torch.nn.Module):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._sync = True
+        self.side_overlap_ratio = None      # two-stream / one-stream time of the probe below (multi-rank GPU jobs)
+        self.launch_form = None             # record of choose_launch_form (multi-rank GPU jobs)
+        if self.world > 1:
+            import socket
+            p0 = next(module.parameters(), None)
+            mine = (socket.gethostname(), p0.device.index) if p0 is not None and p0.is_cuda else None
+            ids = [None] * self.world
+            dist.all_gather_object(ids, mine, group=process_group)
+            check_hw_queues(ids)            # raises on every rank alike
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
@@ -128,7 +244,19 @@ class DataParallel(torch.nn.Module):
                     import warnings
                     warnings.warn("vitamd.ddp: the weight-gradient side stream is serialised with the main stream (shared hardware queue, "
                                   f"two-stream / one-stream time {self.side_overlap_ratio:.2f}); call vitamd.functions.claim_streams(device) "
-                                  "before init_process_group, or (one process per GPU) export GPU_MAX_HW_QUEUES=8")
+                                  "before init_process_group")
+            if self.world > 1 and dev0.type == "cuda":
+                # NT launch form: an explicit VITAMD_NT_PERSISTENT wins; otherwise measured beside this job's own collectives
+                if "VITAMD_NT_PERSISTENT" in os.environ:
+                    from . import ops
+                    self.launch_form = {"chosen": "persistent" if ops.NT_PERSISTENT else "per_tile", "source": "VITAMD_NT_PERSISTENT"}
+                else:
+                    try:
+                        self.launch_form = choose_launch_form(dev0, process_group)
+                    except Exception as e:
+                        import warnings
+                        warnings.warn(f"vitamd.ddp: launch-form measurement failed ({type(e).__name__}: {e}); keeping the default")
+                        self.launch_form = {"chosen": "persistent", "source": "default (measurement failed)"}
         # the broadcast above wrote parameters through .data (no version bump): drop every cached bf16 weight copy
         functions.WEIGHTS.clear()
         self._slot = {}
@@ -153,6 +281,14 @@ class DataParallel(torch.nn.Module):
             yield
         finally:
             self._sync = old
+
+    def diagnostics(self):
+        """what a multi-rank run should report next to its throughput (bench.py `dist`)"""
+        from . import ops, functions
+        return {"side_overlap_ratio": None if self.side_overlap_ratio is None else round(float(self.side_overlap_ratio), 3),
+                "nt_launch_form": self.launch_form or {"chosen": "persistent" if ops.NT_PERSISTENT else "per_tile", "source": "default"},
+                "tn_target_wgs": functions.tn_target_wgs(), "buckets": len(self.buckets),
+                "bucket_mb": round(sum(b.flat.numel() for b in self.buckets) * 4 / (1 << 20), 1)}
 
     def _reduce(self, b, stream=None):
         """enqueue the averaging all-reduce of bucket b (on `stream` if given)"""

@@ -110,7 +110,7 @@ WEIGHTS = WeightCache()
 
 
 ATTN_FUSED_RESID = False  # A/B knob: x1 = x0 + attention written by the attention forward kernel (N <= 256): correct, measured EQUAL (34.47 vs 34.43 ms)
-TN_TARGET_WGS = 252 if ops.NT_PERSISTENT else 128   # workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU).  Whole-step A/B (tools/ab_splits.py) with the PERSISTENT NT launches: 96 -> 31.21 ms, 128 -> 30.86, 160 -> 30.79, 192 -> 30.55, 216 -> 30.44, 252 -> 30.3, 288 -> 31.0, 504 -> 31.8 (with one NT workgroup per tile the optimum was 128-144: 31.45 vs 32.26 at 252)
+TN_TARGET_WGS = None   # None = follow the NT launch form (252 beside persistent NT launches, 128 beside one workgroup per tile), read on every call; an int overrides.  Workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU).  Whole-step A/B (tools/ab_splits.py) with the PERSISTENT NT launches: 96 -> 31.21 ms, 128 -> 30.86, 160 -> 30.79, 192 -> 30.55, 216 -> 30.44, 252 -> 30.3, 288 -> 31.0, 504 -> 31.8 (with one NT workgroup per tile the optimum was 128-144: 31.45 vs 32.26 at 252)
 
 
 def _tn_splits(dW):
@@ -118,10 +118,19 @@ def _tn_splits(dW):
     workgroup per CU (180 of 256) - fewer, longer workgroups write fewer fp32 partial tiles for the reduce pass, and the CUs they
     leave free are taken by the main stream's kernels anyway.  Whole-step A/B (tools/ab_splits.py): 5 splits instead of 7 on the
     36-tile GEMMs of ViT-B: -0.2 ms/step; 3 or fewer lose (36.9 ms at 3, 46 ms at 2)."""
-    if not TN_TARGET_WGS or not SIDE.enabled:      # alone on the chip (no side stream) the kernel's own rule - every CU - is right
+    target = tn_target_wgs()
+    if not target or not SIDE.enabled:      # alone on the chip (no side stream) the kernel's own rule - every CU - is right
         return 0
     ntile = ((dW.shape[0] + 255) // 256) * ((dW.shape[1] + 255) // 256)
-    return max(1, round(TN_TARGET_WGS / ntile))
+    return max(1, round(target / ntile))
+
+
+def tn_target_wgs():
+    """workgroups a layer's weight-gradient GEMM is cut into: the explicit TN_TARGET_WGS, else the value that goes with the current
+    NT launch form (ops.NT_PERSISTENT, a run-time switch)"""
+    if TN_TARGET_WGS is not None:
+        return TN_TARGET_WGS
+    return 252 if ops.NT_PERSISTENT else 128
 
 
 SIDE_POLICY = 0           # A/B knob (tools/ab_side.py): when the MLP weight-gradient GEMMs enter the side stream: 0 = as soon as their inputs exist (beside the
@@ -168,7 +177,7 @@ def ensure_side_overlap(device, attempts=6):
     """Make sure the side stream does not share a hardware queue with the current stream: probe it (streams_overlap) and, if the two
     are serialised, replace it by fresh streams until one runs concurrently.  DataParallel calls this for multi-rank jobs, so the order
     in which the caller initialised RCCL and first used the model does not matter.  Returns the final ratio."""
-    device = torch.device(device)
+    device = _indexed(device)
     ratio = streams_overlap(device)
     kept = []                          # candidates that collided stay alive until the end, so the next one gets another queue
     while ratio > 1.5 and attempts > 0:
@@ -220,6 +229,15 @@ def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad, p_
     return x2, saved, drop
 
 
+def _indexed(device):
+    """torch.device with an explicit index ("cuda" -> the current device), so that streams claimed for "cuda" and looked up by a
+    tensor's device (cuda:0) are the same entry"""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class _Side:
     """A second HIP stream for the weight-gradient GEMMs and bias-gradient column sums.  They
     depend on the input-gradient chain but nothing in that chain depends on them, so running them
@@ -231,6 +249,7 @@ class _Side:
         self.enabled = True
 
     def stream(self, device):
+        device = _indexed(device)
         s = self._streams.get(device)
         if s is None:
             s = self._streams[device] = torch.cuda.Stream(device=device)
@@ -244,9 +263,9 @@ def claim_streams(device):
     """Create the side stream and run a first (empty) kernel on it.  Call this BEFORE torch.distributed.init_process_group("nccl")
     in a multi-GPU job: HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in order of first use, and with
     RCCL's streams created first the side stream was measured to land on the main stream's queue - the two are then serialised
-    with barrier packets, 35.5 instead of 31.4 ms/step on every rank (tools/ddp_bisect.py).  Exporting GPU_MAX_HW_QUEUES=8 before
-    the process touches the GPU has the same effect with one process per GPU (it hung two processes sharing one GPU)."""
-    device = torch.device(device)
+    with barrier packets, 35.5 instead of 31.4 ms/step on every rank (tools/ddp_bisect.py).  (Do NOT raise GPU_MAX_HW_QUEUES instead
+    when ranks share a device: see vitamd.ddp.check_hw_queues.)"""
+    device = _indexed(device)
     with torch.cuda.stream(SIDE.stream(device)):
         torch.zeros(16, device=device).add_(1)
     torch.cuda.current_stream(device).synchronize()

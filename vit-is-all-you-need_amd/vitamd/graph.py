@@ -13,7 +13,9 @@ step in Python + launch overhead eagerly and 1.4 ms replayed; the headline ViT-B
         optim.step()               # p.grad are the graph's static gradient tensors (re-attached every call)
 
 Shapes and dtypes are frozen at capture.  Not for dropout > 0 (the mask seed is a host value baked into the
-captured launches) and not under vitamd.ddp.DataParallel (its bucket hooks run Python during backward).
+captured launches) and not under vitamd.ddp.DataParallel: its per-parameter hooks and the per-layer `layer_ready` calls are Python
+that runs DURING backward and decides, from bucket state, what to enqueue (and torch.distributed work handles are waited for on the
+host in finish()); none of that replays from a graph.  A DataParallel model is refused at construction.
 """
 from __future__ import annotations
 
@@ -29,21 +31,26 @@ class GraphedStep:
         for m in model.modules():
             if float(getattr(m, "dropout", 0.0) or 0.0) > 0.0:      # attention dropout is applied in eval() too (reference transformer.py:28)
                 raise NotImplementedError("GraphedStep with dropout > 0: the mask seed would be frozen into the graph")
+        from .ddp import DataParallel
+        if isinstance(model, DataParallel) or any(isinstance(m, DataParallel) for m in model.modules()):
+            raise NotImplementedError("GraphedStep around vitamd.ddp.DataParallel: the bucket hooks run Python during backward (see the module docstring)")
         self.model, self.loss_fn = model, loss_fn
         self.x = example_x.detach().clone()
         self.y = example_y.detach().clone()
         self.params = [p for p in model.parameters() if p.requires_grad]
-        # warm up on a side stream (allocator pools, hipFuncSetAttribute one-time calls, weight-cache groups)
+        # warm up (allocator pools, hipFuncSetAttribute one-time calls, weight-cache groups) ON THE STREAM THE CAPTURE WILL USE: autograd's
+        # AccumulateGrad nodes remember the stream they were created on, and nodes created on another stream than the capturing one
+        # made every replayed backward warn about (and potentially synchronise on) a stream mismatch
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(max(1, warmup)):
                 self._eager()
+            model.zero_grad(set_to_none=True)      # so the captured backward ASSIGNS fresh gradient tensors
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        model.zero_grad(set_to_none=True)          # so the captured backward ASSIGNS fresh gradient tensors
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=s):
             self.loss = self._eager(zero=False)
         self.grads = [p.grad for p in self.params]
 

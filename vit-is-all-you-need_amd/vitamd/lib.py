@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitamd.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c = ctypes
 _P, _I, _F, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_ulonglong
@@ -35,7 +35,7 @@ SIGNATURES = {
     "vitamd_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "vitamd_layernorm_bwd_dropout": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],
     "vitamd_layernorm_bwd_xhat": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P],
-    "vitamd_linear_dropout_resid_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _P],
+    "vitamd_linear_dropout_resid_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _I, _P],
     "vitamd_cast_f32_bf16_dropout": [_P, _P, _L, _F, _U64, _P],
     "vitamd_cast_f32_bf16": [_P, _P, _L, _P],
     "vitamd_dropout_bf16": [_P, _P, _L, _L, _F, _U64, _P],
@@ -63,10 +63,10 @@ class VitamdError(RuntimeError):
 EXP_LIB_PATH = os.path.join(_HERE, "libvitamd_exp.so")
 
 
-def build(verbose: bool = False, experimental: bool = True) -> str:
-    """Compile libvitamd.so for gfx950 with hipcc (cross-compiles without a GPU) and, unless told otherwise, libvitamd_exp.so: the
-    same sources with -DVITAMD_EXPERIMENTAL (measured alternative kernels + vitamd_set_debug) for the A/B tools under tools/.
-    The product and the tests of the product load libvitamd.so only."""
+def build(verbose: bool = False, experimental: bool = False) -> str:
+    """Compile libvitamd.so for gfx950 with hipcc (cross-compiles without a GPU).  experimental=True also builds libvitamd_exp.so: the
+    same sources with -DVITAMD_EXPERIMENTAL (measured alternative kernels + vitamd_set_debug) for the A/B tools under tools/ - those
+    call build(experimental=True) themselves through use_experimental().  The product and its tests load libvitamd.so only."""
     for args in ([], ["EXPERIMENTAL=1"])[: 2 if experimental else 1]:
         r = subprocess.run(["make", "-C", CSRC, "-j8", *args], capture_output=True, text=True)
         if verbose or r.returncode != 0:
@@ -82,6 +82,8 @@ def use_experimental():
     global LIB_PATH
     if _lib is not None:
         raise VitamdError("use_experimental() must come before the first load()")
+    if not os.path.exists(EXP_LIB_PATH):
+        build(experimental=True)
     LIB_PATH = EXP_LIB_PATH
 
 

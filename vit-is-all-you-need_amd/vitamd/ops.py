@@ -13,7 +13,9 @@ EPI_BIAS_BF16, EPI_GELU, EPI_RESID_F32, EPI_DGELU, EPI_PATCH_F32, EPI_F32, EPI_G
 # Large NT GEMMs are launched persistent by default (one workgroup per CU: -0.3 ms/step inside the training step and the reason the
 # weight-gradient stream can use the whole chip).  A persistent workgroup whose CU is held by another
 # long-running kernel starts late with its whole tile list still to do, so the form is sensitive to resident foreign kernels
-# (DESIGN.md section 7); VITAMD_NT_PERSISTENT=0 (or ops.NT_PERSISTENT = False) selects one workgroup per tile instead.
+# (DESIGN.md section 7); VITAMD_NT_PERSISTENT=0 (or ops.NT_PERSISTENT = False at any time: it is read on every call, and the
+# weight-gradient split rule of functions._tn_splits follows it) selects one workgroup per tile instead.  vitamd.ddp.DataParallel
+# measures both forms beside its collectives at construction and sets it for multi-rank jobs (ddp.choose_launch_form).
 import os as _os
 NT_PERSISTENT = _os.environ.get("VITAMD_NT_PERSISTENT", "1") != "0"
 LN_EPS = 1e-5
@@ -237,7 +239,7 @@ def linear_dropout_resid(a, b, bias, resid, dropout):
     N = b.shape[0]
     out = torch.empty((M, N), dtype=F32, device=a.device)
     code = _L().vitamd_linear_dropout_resid_bf16(_p(a), _p(b), _p(out), _p(bias), _p(resid), M, N, K, float(dropout[0]), int(dropout[1]),
-                                                 _stream())
+                                                 0 if NT_PERSISTENT else 512, _stream())
     _lib.check(code, f"linear_dropout_resid[M={M},N={N},K={K}]")
     return out
 
