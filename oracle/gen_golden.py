@@ -479,10 +479,75 @@ def gen_autocast_fixture(RT, TV):
     save("ref_autocast_bf16.pt", out)
 
 
+def gen_sdpa_fixture():
+    """F.scaled_dot_product_attention exactly as the reference calls it (transformer.py:27-28: default scale, no mask, dropout 0) on the
+    ViT-B head geometry (B 2, N 197, H 12, head_dim 64), forward and dq / dk / dv: once in fp32 and once in bf16 (what the reference's
+    SDPA sees under autocast: the QKV Linear's bf16 output), both from the SAME bf16-representable inputs.  The distance between the
+    two is the reference's own bf16 floor for this op; the HIP attention kernels are held to it instead of to an
+    argument about where bf16 roundings sit.  Inputs are regenerated from seeds by the test (oracle/weights.py); outputs are stored as
+    every-7th-element samples."""
+    import torch.nn.functional as F
+    from einops import rearrange
+    B, N, H, dh, seed = 2, 197, 12, 64, 41
+    qkv = (W.normal(seed, "qkv", (B, N, 3 * H * dh)) * 1.5).bfloat16().float()
+    d_o = W.normal(seed, "d_o", (B, N, H * dh)).bfloat16().float()
+
+    def run(dtype):
+        t = qkv.to(dtype).detach().clone().requires_grad_(True)
+        q, k, v = rearrange(t, "b n (qkv h d) -> qkv b h n d", qkv=3, h=H)          # reference transformer.py:27
+        o = rearrange(F.scaled_dot_product_attention(q, k, v), "b h n d -> b n (h d)")   # :28-29
+        (o.float() * d_o).sum().backward() if dtype == torch.float32 else o.backward(d_o.to(dtype))
+        return o.detach().float(), t.grad.detach().float()
+
+    o32, g32 = run(torch.float32)
+    o16, g16 = run(torch.bfloat16)
+    D = H * dh
+    s7 = lambda t: t.flatten()[::7].clone()                                      # noqa: E731
+    parts = {"dq": slice(0, D), "dk": slice(D, 2 * D), "dv": slice(2 * D, 3 * D)}
+    out = {"config": {"B": B, "N": N, "H": H, "head_dim": dh, "seed": seed, "input_scale": 1.5, "sample_stride": 7},
+           "fp32": {"o": s7(o32), **{k: s7(g32[..., sl].contiguous()) for k, sl in parts.items()}},
+           "bf16": {"o": s7(o16), **{k: s7(g16[..., sl].contiguous()) for k, sl in parts.items()}},
+           "ref_bf16_floor": {"o": rel_l2(o16, o32), **{k: rel_l2(g16[..., sl], g32[..., sl]) for k, sl in parts.items()}}}
+    print("reference SDPA bf16-vs-fp32 floor:", {k: f"{v:.2e}" for k, v in out["ref_bf16_floor"].items()})
+    save("sdpa_b197.pt", out)
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def gen_autocast_b224(TV):
+    """Adds the headline shape (ViT-B/16, 224 px, 12 layers, batch 2: the inputs of vit_b224.pt) to ref_autocast_bf16.pt: logits, loss and
+    every parameter gradient of the unmodified reference under torch.autocast(cpu, bf16).  The other entries of
+    the file are kept as they are."""
+    path = os.path.join(OUT, "ref_autocast_bf16.pt")
+    out = torch.load(path, weights_only=True)
+    cfg = TV.ViTConfig(224, 3, 16, "B", 1, 0.0)
+    tc = cfg.trans_config
+    model = TV.ViTClassifier(cfg, num_classes=1000)
+    seed, batch = 14, 2
+    model.load_state_dict(W.classifier_state(seed, 3, 16, cfg.n_patches, 1, tc.n_layers, tc.n_embd, 1000), strict=True)
+    images, labels = W.normal(seed, "images", (batch, 3, 224, 224)), W.randint(seed, "labels", (batch,), 1000)
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        logits = model(images)
+        loss = torch.nn.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    out["vit_b224"] = {"logits": logits.detach().float(), "loss": float(loss),
+                       "grads": {k: summarize(p.grad) for k, p in model.named_parameters()}}       # full tensors up to 65 536 elements (vectors), samples + norms beyond
+    save("ref_autocast_bf16.pt", out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--sdpa-only" in sys.argv:
+        gen_sdpa_fixture()
+        return
     RT, TV, RU = import_reference()
+    if "--autocast-b224-only" in sys.argv:
+        gen_autocast_b224(TV)
+        return
     if "--autocast-only" in sys.argv:          # add the round-2 fixture without touching the others
         gen_autocast_fixture(RT, TV)
         return
@@ -490,6 +555,8 @@ def main():
         gen_blocks_depth_fixture()
         return
     gen_autocast_fixture(RT, TV)
+    gen_autocast_b224(TV)
+    gen_sdpa_fixture()
     gen_transformer_fixtures(RT)
     gen_classifier_fixture(TV, "vit_s32.pt", 32, "S", 10, 64, seed=13, full_grads=True)   # BASELINE config 1
     gen_classifier_fixture(TV, "vit_b224.pt", 224, "B", 1000, 2, seed=14)                 # BASELINE config 2 shape

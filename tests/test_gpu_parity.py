@@ -541,6 +541,15 @@ def test_vs_reference_own_bf16_autocast_outputs(hip):
     assert abs(loss - r["loss"]) < 2 * floor["loss_abs"] + 2e-3
     for k, want in r["grads"].items():
         assert _err(grads[k], want) < 2 * floor["grads"][k] + 5e-3, k
+    # the headline shape: 12-layer ViT-B/16 at 224 px, batch 2, against the reference's own autocast run
+    g = load_golden("vit_b224.pt")
+    floor = g["ref_bf16_floor"]
+    logits, loss, grads, _ = _run_classifier(g)
+    r = ref["vit_b224"]
+    assert O.rel_l2(logits, r["logits"]) < 2 * floor["logits"] + 2e-3
+    assert abs(loss - r["loss"]) < 2 * floor["loss_abs"] + 2e-3
+    for k, want in r["grads"].items():
+        assert _err(grads[k], want) < 2 * floor["grads"][k] + 5e-3, k
 
 
 def test_reference_loop_autocast_and_gradscaler_are_transparent(hip):

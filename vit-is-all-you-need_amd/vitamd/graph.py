@@ -51,7 +51,9 @@ class GraphedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=s):
-            self.loss = self._eager(zero=False)
+            # detached: the static loss tensor must not keep the captured step's autograd graph (and with it the parameters'
+            # AccumulateGrad nodes, bound to the capture stream) alive - an eager backward on another stream afterwards would warn
+            self.loss = self._eager(zero=False).detach()
         self.grads = [p.grad for p in self.params]
 
     def _eager(self, zero=True):
