@@ -22,5 +22,5 @@ res = {k: [] for k in cfgs}
 for r in range(4):
     for k in cfgs:
         F.TN_TARGET_WGS = k; res[k].append(timed())
-F.TN_TARGET_WGS = 252
+F.TN_TARGET_WGS = None
 for k in cfgs: print("target workgroups=%s median %.2f ms/step  %s" % (k, statistics.median(res[k]), ["%.2f" % v for v in res[k]]))

@@ -4,7 +4,11 @@ overlap gain = alone_P + alone_TN - together."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
+if os.environ.get("TN_SMALL_RING"):        # co-residency experiment: the 5-slot-ring (80 KiB) weight-gradient kernel of the experimental library
+    from vitamd import lib as _explib; _explib.use_experimental()
 from vitamd import ops, functions as F
+if os.environ.get("TN_SMALL_RING"):
+    _explib.load().vitamd_set_debug(-2147483648)     # bit 31
 dev = torch.device("cuda")
 B, N, H, D = 256, 197, 12, 768
 M = B * N
@@ -41,10 +45,12 @@ def run(main_fn, side_fn, k=6, reps=5):
         e.record(); torch.cuda.synchronize()
         best = min(best, s.elapsed_time(e) / k * 1e3)
     return best
+ref = None
 for wgs in (128, 252):
     F.TN_TARGET_WGS = wgs
     t = tn(F._tn_splits(dW1))
     t(); torch.cuda.synchronize()
+    if ref is None: ref = dW1.clone(); print("dW1 checksum %.6e" % float(dW1.double().abs().sum()))
     ta = run(None, t)
     print(f"TN dW1 cut into ~{wgs} workgroups alone: {ta:.0f} us per launch")
     for name, p in partners.items():

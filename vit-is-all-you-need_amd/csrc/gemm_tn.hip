@@ -271,6 +271,12 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
 #ifdef VITAMD_EXPERIMENTAL
   {   // A/B knobs: bit 6 = 16x16x32 round-1 form; bits 26-28: 1-3 timing-only ablations, 4 = ping-pong on 16x16x32, 5 = round-1 LDS-DMA, 6 = round-1 VGPR-staged, 7 = ping-pong D = 6
     const int sel = (g_vitamd_debug >> 26) & 7;
+    if (use_ws && (g_vitamd_debug & 0x80000000)) {   // bit 31: co-residency experiment: a 5-slot ring (80 KiB) leaves room for ONE attention-backward workgroup (74 KiB, 4 x 128 registers) on the CU
+      if (int e = set_lds(gemm_tn_pp_kernel<true, 5, 3>, 5 * QSLOT)) return e;
+      hipLaunchKernelGGL((gemm_tn_pp_kernel<true, 5, 3>), grid, block, 5 * QSLOT, stream, a, tiles_p, tiles_q, splits);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits, a.accumulate);
+      return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+    }
     if (use_ws && ((g_vitamd_debug & 64) || sel)) {
       if (g_vitamd_debug & 64) { if (int e = set_lds(gemm_tn16_kernel<true>, lds)) return e; hipLaunchKernelGGL(gemm_tn16_kernel<true>, grid, block, lds, stream, a, tiles_p, tiles_q, splits); }
       else {

@@ -137,6 +137,10 @@ SIDE_POLICY = 0           # A/B knob (tools/ab_side.py): when the MLP weight-gra
                           # input-gradient GEMMs), 1 = both after dgrad-fc1 (beside LayerNorm / attention backward), 2 = dW2 beside dgrad-fc1, dW1 after it
 LN_BWD_XHAT = True        # A/B knob (tools/ab_gelu.py): LayerNorm backward reads xhat from the saved bf16 LN output instead of recomputing it from fp32 x
 GELU_STORED_GRAD = True   # A/B knob (tools/ab_gelu.py); False = keep the pre-activation and evaluate gelu' in the backward
+DEFER_RESID = True        # inside a stack: fc2 writes bf16 y and the NEXT layer's first LayerNorm adds it to the residual stream (x2 = x1 + y, the same
+                          # fp32 + bf16 sum the fused epilogue formed: bit-identical).  The same HBM bytes in total, but they move from the GEMM's
+                          # epilogue (40 fp32 loads + 40 fp32 stores per wave and tile on the CU's one path to L1, matrix pipes idle) into an
+                          # HBM-bound LayerNorm kernel, and fc2 becomes a plain bias GEMM: whole-step A/B (tools/ab_flags.py) in DESIGN.md section 4.2
 
 
 def streams_overlap(device, side=None):
@@ -200,15 +204,17 @@ def new_seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
-def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad, p_attn=0.0, p_mlp=0.0):
+def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad, p_attn=0.0, p_mlp=0.0, pending=None, defer=False):
     """x0 fp32 [M,D] -> x2 fp32 [M,D], the tensors backward needs, and the dropout record
     (p_attn, seed_attn, p_mlp, seed_mlp).  p_attn: SDPA dropout_p (transformer.py:28); p_mlp: the
-    nn.Dropout after fc2 (transformer.py:40)."""
+    nn.Dropout after fc2 (transformer.py:40).
+    pending: bf16 [M,D] MLP output of the layer below that has not been added to x0 yet (this layer's first LayerNorm adds it).
+    defer: return (x1, y) with y = bf16 fc2 output instead of x2 = x1 + y (the caller hands y to the next layer as `pending`)."""
     drop = (p_attn, new_seed() if p_attn > 0 else 0, p_mlp, new_seed() if p_mlp > 0 else 0)
     wqkv_b, _ = WEIGHTS.get(wqkv, need_grad)
     w1_b, _ = WEIGHTS.get(w1, need_grad)
     w2_b, _ = WEIGHTS.get(w2, need_grad)
-    _, a, mean1, rstd1 = ops.layernorm_fwd(x0)                                   # LN1            transformer.py:43
+    x0, a, mean1, rstd1 = ops.layernorm_fwd(x0, addend=pending)                  # (residual of the layer below +) LN1   transformer.py:43-44
     qkv = ops.gemm_nt(a, wqkv_b, ops.EPI_BIAS_BF16, bias=bqkv)                   # fused QKV      transformer.py:27
     if ATTN_FUSED_RESID and N <= ops.ATTN_RESID_MAX_N:
         # SDPA (transformer.py:28-29) with the residual add of transformer.py:44 in its epilogue: the LayerNorm below then reads the
@@ -221,12 +227,15 @@ def layer_forward(x0, wqkv, bqkv, w1, b1, w2, b2, B, N, H, causal, need_grad, p_
     # fc1 + GELU (transformer.py:37-38); `pre` holds bf16(gelu'(fc1 out)) for the backward - the derivative is evaluated
     # here, where its exp is shared with the erf and the VALU work hides under the output stores (-85 us per layer in dgrad fc2)
     pre, h = ops.gemm_nt(bln, w1_b, ops.EPI_GELU_DG if GELU_STORED_GRAD else ops.EPI_GELU, bias=b1)
+    y = None
     if p_mlp > 0:
         x2 = ops.linear_dropout_resid(h, w2_b, b2, x1, drop[2:])                 # fc2 + dropout + residual
+    elif defer:
+        x2, y = x1, ops.gemm_nt(h, w2_b, ops.EPI_BIAS_BF16, bias=b2)             # fc2; x2 = x1 + y is formed by the next layer's LayerNorm
     else:
         x2 = ops.gemm_nt(h, w2_b, ops.EPI_RESID_F32, bias=b2, aux=x1)            # fc2 + residual transformer.py:39,44
     saved = (x0, mean1, rstd1, a, qkv, o, lse, x1, mean2, rstd2, bln, pre, h) if need_grad else None
-    return x2, saved, drop
+    return (x2, y) if defer else x2, saved, drop
 
 
 def _indexed(device):
@@ -461,10 +470,13 @@ class TransformerStackFn(torch.autograd.Function):
         cur = _f32c(x).view(B * N, D)
         saved_all, drops = [], []
         WEIGHTS.prepare([params[6 * i + j] for i in range(L) for j in (0, 2, 4)], need_grad)
+        pending = None
         for i in range(L):
             wqkv, bqkv, w1, b1, w2, b2 = params[6 * i: 6 * i + 6]
-            cur, saved, drop = layer_forward(cur, wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads, causal, need_grad,
-                                             p_attn, p_mlp)
+            defer = DEFER_RESID and i + 1 < L and p_mlp == 0          # the last layer (no LayerNorm follows) and dropout keep the fused epilogue
+            out, saved, drop = layer_forward(cur, wqkv, _f32c(bqkv), w1, _f32c(b1), w2, _f32c(b2), B, N, n_heads, causal, need_grad,
+                                             p_attn, p_mlp, pending=pending, defer=defer)
+            cur, pending = out if defer else (out, None)
             drops.append(drop)
             if need_grad:
                 saved_all.extend(saved)
