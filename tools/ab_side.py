@@ -17,6 +17,10 @@ def timed(n=5):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 cfgs = {"policy0_wgs252": (0, 252, True), "policy1_wgs252": (1, 252, True), "policy2_wgs252": (2, 252, True), "policy0_wgs192": (0, 192, True),
         "no side stream": (0, 252, False)}
+if len(sys.argv) > 1:          # explicit list: policy:wgs ...
+    cfgs = {"policy0_wgs252": (0, 252, True)}
+    for a in sys.argv[1:]:
+        pol, wgs = a.split(":"); cfgs[f"policy{pol}_wgs{wgs}"] = (int(pol), int(wgs), True)
 for _ in range(3): step()
 res = {k: [] for k in cfgs}
 for r in range(5):
