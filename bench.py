@@ -107,7 +107,7 @@ def kernel_roofline(dev):
 
 
 PMC_DIR = os.path.join("profiles", "r03")
-NT_ALGO_MB = (313 + 702 + 625 + 702 + 392 + 313) / 6.0     # algorithmic MB per launch, mean over the six NT launches of a layer
+NT_ALGO_MB = (12 * 313 + 12 * 702 + 12 * 702 + 12 * 392 + 12 * 313 + 11 * 392 + 625) / 72.0     # algorithmic MB per launch, weighted over the 72 large NT launches of a step: QKV 313, fc1+GELU 702, dgrad-fc2 702, dgrad-fc1 392, dgrad-QKV 313, fc2 392 (bf16 out; the last layer's fused residual 625)
 
 
 def csrc_sha16():

@@ -137,6 +137,33 @@ def test_gemm_nt_epilogues(hip, tile):
 
 
 @pytest.mark.parametrize("M", [256 * 197, 50000, 320 * 100 + 7])
+@pytest.mark.parametrize("M,N,K", [(320 * 300 + 77, 2312, 192), (256 * 300 + 5, 1288, 128), (50432, 3072, 1536)])
+def test_gemm_nt_seam_form_exact_on_ragged_shapes(hip, M, N, K):
+    """The seam form of the persistent kernel (gemm_nt_seam.h: short K loop, >= 3 tiles per CU) on shapes whose last tile row AND last tile
+    column are ragged (N % 8 == 0 only): masked rows / columns are out-of-range stores, bias columns past N read as zero, the pipeline
+    fill of a tile is requested during the previous tile's epilogue.  Integer operands: exact, and equal to one workgroup per tile."""
+    from vitamd import ops
+    a, b = ints((M, K), -2, 2, 61), ints((N, K), -2, 2, 62)
+    bias = ints((N,), -4, 4, 63)
+    ad, bd, biasd = a.to(dev(), BF16), b.to(dev(), BF16), bias.to(dev())
+    ref = (ad.float() @ bd.float().t()) + biasd                    # exact in fp32 (|sum| <= 4 K)
+    for _ in range(2):                                             # twice: a race would not repeat
+        y = ops.gemm_nt(ad, bd, ops.EPI_BIAS_BF16, bias=biasd)
+        assert torch.equal(y.float(), ref)
+    assert torch.equal(y, ops.gemm_nt(ad, bd, ops.EPI_BIAS_BF16, bias=biasd, tile=512))
+    pre, h = ops.gemm_nt(ad, bd, ops.EPI_GELU_DG, bias=biasd)
+    pre2, h2 = ops.gemm_nt(ad, bd, ops.EPI_GELU_DG, bias=biasd, tile=512)
+    assert torch.equal(pre, pre2) and torch.equal(h, h2)
+    if N % 256 == 0:
+        fac = (ints((M, N), -2, 2, 64) * 0.5).to(dev(), BF16)
+        c1, c2 = torch.zeros(N, device=dev()), torch.zeros(N, device=dev())
+        d1 = ops.gemm_nt(ad, bd, ops.EPI_DMUL, aux=fac, colsum=c1)
+        d2 = ops.gemm_nt(ad, bd, ops.EPI_DMUL, aux=fac, colsum=c2, tile=512)
+        assert torch.equal(d1, d2)
+        assert torch.equal(d1.float(), (ad.float() @ bd.float().t()) * fac.float())
+        assert O.rel_l2(c1.cpu(), c2.cpu()) < 1.0e-6               # column sums: atomics, order differs
+
+
 def test_gemm_nt_tall_tile_exact(hip, M):
     """N = 768 outputs at large M are dispatched to the 320x256-tile kernel (fewer rounds of the 256 CUs); integer operands
     make the bf16 / fp32 results exact, so any mis-mapped row or column shows.  Checked against the 256x256 kernel too."""

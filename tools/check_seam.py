@@ -1,4 +1,4 @@
-"""Exactness of the seam kernel (experimental tile codes 24 / 25) against one-workgroup-per-tile launches of the ping-pong kernel: integer-valued
+"""tools/check_seam.py - exactness of the seam kernel (experimental tile codes 24 / 25) against one-workgroup-per-tile launches of the ping-pong kernel: integer-valued
 operands, every epilogue, three repetitions each (a race shows as a count that changes between repetitions)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
