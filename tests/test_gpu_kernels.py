@@ -136,7 +136,6 @@ def test_gemm_nt_epilogues(hip, tile):
     assert O.rel_l2(got[:, extra:], want) < 7.7e-6
 
 
-@pytest.mark.parametrize("M", [256 * 197, 50000, 320 * 100 + 7])
 @pytest.mark.parametrize("M,N,K", [(320 * 300 + 77, 2312, 192), (256 * 300 + 5, 1288, 128), (50432, 3072, 1536)])
 def test_gemm_nt_seam_form_exact_on_ragged_shapes(hip, M, N, K):
     """The seam form of the persistent kernel (gemm_nt_seam.h: short K loop, >= 3 tiles per CU) on shapes whose last tile row AND last tile
@@ -164,6 +163,7 @@ def test_gemm_nt_seam_form_exact_on_ragged_shapes(hip, M, N, K):
         assert O.rel_l2(c1.cpu(), c2.cpu()) < 1.0e-6               # column sums: atomics, order differs
 
 
+@pytest.mark.parametrize("M", [256 * 197, 50000, 320 * 100 + 7])
 def test_gemm_nt_tall_tile_exact(hip, M):
     """N = 768 outputs at large M are dispatched to the 320x256-tile kernel (fewer rounds of the 256 CUs); integer operands
     make the bf16 / fp32 results exact, so any mis-mapped row or column shows.  Checked against the 256x256 kernel too."""
