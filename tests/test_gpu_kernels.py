@@ -145,7 +145,7 @@ def test_gemm_nt_seam_form_exact_on_ragged_shapes(hip, M, N, K):
     a, b = ints((M, K), -2, 2, 61), ints((N, K), -2, 2, 62)
     bias = ints((N,), -4, 4, 63)
     ad, bd, biasd = a.to(dev(), BF16), b.to(dev(), BF16), bias.to(dev())
-    ref = (ad.float() @ bd.float().t()) + biasd                    # exact in fp32 (|sum| <= 4 K)
+    ref = ((ad.float() @ bd.float().t()) + biasd).to(BF16).float()   # exact in fp32 (|sum| <= 4 K), then the output's one bf16 rounding
     for _ in range(2):                                             # twice: a race would not repeat
         y = ops.gemm_nt(ad, bd, ops.EPI_BIAS_BF16, bias=biasd)
         assert torch.equal(y.float(), ref)
@@ -159,7 +159,7 @@ def test_gemm_nt_seam_form_exact_on_ragged_shapes(hip, M, N, K):
         d1 = ops.gemm_nt(ad, bd, ops.EPI_DMUL, aux=fac, colsum=c1)
         d2 = ops.gemm_nt(ad, bd, ops.EPI_DMUL, aux=fac, colsum=c2, tile=512)
         assert torch.equal(d1, d2)
-        assert torch.equal(d1.float(), (ad.float() @ bd.float().t()) * fac.float())
+        assert torch.equal(d1.float(), ((ad.float() @ bd.float().t()).to(BF16).float() * fac.float()).to(BF16).float())
         assert O.rel_l2(c1.cpu(), c2.cpu()) < 1.0e-6               # column sums: atomics, order differs
 
 
