@@ -331,6 +331,7 @@ def main():
                        "global_batch": PER_GPU_BATCH * world, "parallelism": f"dp{world}"},
             "model_flops_frac_of_peak": round(value / world * GFLOP_PER_IMAGE / 1e3 / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(loss_val, 4), "dist": dist_info,
+            "nt_seam_probe": __import__("vitamd.ops", fromlist=["SEAM_PROBE"]).SEAM_PROBE.get(dev.index),     # start-up A/B of the seam form on this device (vitamd.ops.seam_probe)
         }
         if not args.no_roofline:
             out["roofline"] = kernel_roofline(dev)

@@ -46,7 +46,7 @@ int vitamd_abi_version(void);
  * one workgroup per tile.  Auto launches problems with more tiles than CUs PERSISTENT (one workgroup per CU walking a strided tile
  * list: faster next to a second stream's kernels, but sensitive to CUs held by other long-running kernels, e.g. collectives; with a
  * short reduction dim (K <= 1536) and >= 3 tiles per CU in the form that requests the next tile's operands before the epilogue);
- * 512 = auto without persistent launches.
+ * 512 = auto without persistent launches; 1024 = auto with persistent launches but without the seam form.
  * Forward of nn.Linear (x W^T + b): A = x, B = W.  Input gradient (dy W): A = dy, B = W^T. */
 int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
                         float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,

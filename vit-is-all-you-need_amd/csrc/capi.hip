@@ -26,9 +26,9 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
   if (epi == 7) epi = EPI_DGELU;
   GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, VITAMD_GDBG, 0u, 1.0f, 0u, 0u, 0, dg};
   #ifdef VITAMD_EXPERIMENTAL
-  if (!(tile >= 0 && tile <= 25) && tile != 128 && tile != 256 && tile != 257 && tile != 320 && tile != 512) return VITAMD_ERR_ARG;
+  if (!(tile >= 0 && tile <= 25) && tile != 128 && tile != 256 && tile != 257 && tile != 320 && tile != 512 && tile != 1024) return VITAMD_ERR_ARG;
 #else
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) return VITAMD_ERR_ARG;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024) return VITAMD_ERR_ARG;
 #endif
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
 }
@@ -56,7 +56,7 @@ static bool dropout_params(float p, unsigned& thresh, float& scale) {
 // fc2 with dropout: out f32 = resid + dropout_p(bf16(A.B^T + bias)) — reference transformer.py:39-40,44
 extern "C" int vitamd_linear_dropout_resid_bf16(const void* A, const void* B, float* out, const float* bias, const float* resid,
                                                 int M, int N, int K, float dropout_p, unsigned long long seed, int tile, void* stream) {
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) return VITAMD_ERR_ARG;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024) return VITAMD_ERR_ARG;
   GemmNtArgs p{A, B, out, nullptr, bias, resid, nullptr, M, N, K, N, EPI_RESID_F32, 0, 0, 0, tile, VITAMD_GDBG, 0u, 1.0f,
                (unsigned)seed, (unsigned)(seed >> 32), 0, 0};
   if (!dropout_params(dropout_p, p.drop_thresh, p.drop_scale)) return VITAMD_ERR_ARG;

@@ -357,6 +357,8 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   // tile selector of the C ABI: 0 = auto, 128 = the 128x128 kernel, 256 / 320 = the ping-pong kernel on 256- / 320-row tiles
   // (experimental builds: further codes select the measured alternatives, see experimental/gemm_nt_variants.inc)
   int tile = p.tile;
+  const bool no_seam = tile == 1024;      // ABI code 1024: the automatic choice with persistent launches but WITHOUT the seam form (A/B and start-up probe: ops.seam_probe)
+  if (no_seam) tile = 0;
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool pp_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0;
   constexpr bool tall_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU;
@@ -382,7 +384,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
     // fc1+GELU 316 -> 298, dgrad-fc2 298 -> 268 (K = 768, 7-10 tiles per CU); equal or 4 % slower where a CU sees only two tiles of a long K loop
     // (dgrad-fc1 K = 3072, dgrad-QKV K = 2304), which therefore stay on the form below.  Bit-identical results.  (dbg bit 17: off)
     if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
-      if (seam_ok(p) && p.K <= 1536 && !(VITAMD_DBG(p) & 0x20000)) {
+      if (!no_seam && seam_ok(p) && p.K <= 1536 && !(VITAMD_DBG(p) & 0x20000)) {
         const int cus = device_cus();
         if constexpr (EPI != EPI_DGELU) {
           if (prefer_tall(p) && (long)((p.M + 319) / 320) * ((p.N + 255) / 256) >= 3L * cus) return launch_seam<EPI, 10>(p, stream, cus);
@@ -425,7 +427,7 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   // One big-tile workgroup per CU means a launch runs in whole rounds of 256 tiles; a last round that is mostly empty idles most of
   // the chip for a full tile time.  Two remedies live here: the tile height (prefer_tall) and the tail split below.
   const int CUS = device_cus();
-  const bool tall = (p.tile == 0 || p.tile == 512) && prefer_tall(p);
+  const bool tall = (p.tile == 0 || p.tile == 512 || p.tile == 1024) && prefer_tall(p);
   const int bm = tall ? 320 : 256;
   const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + 255) / 256;
   const long big_tiles = (long)tiles_m * tiles_n;
@@ -436,7 +438,7 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
   // of the side stream already fill the backward tails, +0.2 ms on fc1+GELU at 7.4 rounds of 320-row tiles (the 128x128 kernel's
   // direct-store GELU epilogue costs more than the 0.6 idle round).  Experimental builds: vitamd_set_debug bit 7 turns it off, bit 4 forces it.
   const bool split_on = (VITAMD_DBG(p) & 16) != 0 || (!(VITAMD_DBG(p) & 128) && p.epi == EPI_RESID_F32 && !tall);
-  if ((p.tile == 0 || p.tile == 512) && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
+  if ((p.tile == 0 || p.tile == 512 || p.tile == 1024) && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
     const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
     const int rows_a = panels_a * bm;
     if (panels_a > 0 && rows_a < p.M) {
