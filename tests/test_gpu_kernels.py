@@ -201,6 +201,27 @@ def test_gemm_nt_tall_tile_gelu_epilogues_match_256(hip):
         assert O.rel_l2(c1.cpu(), c2.cpu()) < 1.0e-6          # column sums: atomics, order differs
 
 
+def test_seam_probe_and_tile_code_1024(hip):
+    """ops.seam_probe times the seam form against the plain persistent form and sets ops.NT_SEAM; tile code 1024 (persistent, no seams) gives the
+    same bits as the automatic choice and as one workgroup per tile."""
+    from vitamd import ops
+    keep = ops.NT_SEAM
+    try:
+        ops.NT_SEAM = None
+        on = ops.seam_probe(dev(), rows=12288, reps=1)
+        rec = ops.SEAM_PROBE[torch.cuda.current_device()]
+        assert on == rec["enabled"] == ops.NT_SEAM and rec["seam_us"] > 0 and rec["plain_us"] > 0
+        a, b = r16(randn((256 * 24 + 3, 768), 91)).to(dev(), BF16), r16(randn((2304, 768), 92, 0.05)).to(dev(), BF16)
+        bias = randn((2304,), 93).to(dev())
+        y0 = ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias, tile=0)
+        assert torch.equal(y0, ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias, tile=1024))
+        assert torch.equal(y0, ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias, tile=512))
+        ops.NT_SEAM = False                                          # switched off: the host wrapper asks for code 1024 by itself
+        assert torch.equal(y0, ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias))
+    finally:
+        ops.NT_SEAM = keep
+
+
 def test_gemm_nt_rejects_bad_shapes(hip):
     from vitamd import ops, lib
     a = torch.zeros((64, 100), device=dev(), dtype=BF16)
