@@ -211,7 +211,7 @@ def test_seam_probe_and_tile_code_1024(hip):
         on = ops.seam_probe(dev(), rows=12288, reps=1)
         rec = ops.SEAM_PROBE[torch.cuda.current_device()]
         assert on == rec["enabled"] == ops.NT_SEAM and rec["seam_us"] > 0 and rec["plain_us"] > 0
-        a, b = r16(randn((256 * 24 + 3, 768), 91)).to(dev(), BF16), r16(randn((2304, 768), 92, 0.05)).to(dev(), BF16)
+        a, b = r16(randn((256 * 120 + 3, 768), 91)).to(dev(), BF16), r16(randn((2304, 768), 92, 0.05)).to(dev(), BF16)
         bias = randn((2304,), 93).to(dev())
         y0 = ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias, tile=0)
         assert torch.equal(y0, ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias, tile=1024))
