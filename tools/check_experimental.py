@@ -86,5 +86,19 @@ for (B, N, H) in [(2, 33, 2), (3, 64, 1), (2, 100, 3), (1, 160, 2), (2, 197, 4),
     L.vitamd_set_debug(0)
     if not torch.equal(got, ref) or not torch.allclose(db, db2, rtol=1e-5, atol=1e-5):
         bad.append(("attn-bwd-pipe", B, N, H))
+# round 3: explicit seam-kernel codes (24 = 256-row tiles, 25 = 320-row) and the 5-slot-ring weight-gradient kernel (debug bit 31)
+for (M, N, K, tile) in [(512, 512, 128, 24), (256 * 40, 768, 768, 24), (320 * 30 + 64, 768, 768, 25), (512, 512, 128, 25)]:
+    a, b = ints((M, K), -1, 1, 5), ints((N, K), -1, 1, 6)
+    out = ops.gemm_nt(a.to(dev, BF16), b.to(dev, BF16), ops.EPI_BIAS_BF16, tile=tile)
+    if not torch.equal(out.float().cpu(), (a @ b.t()).to(BF16).float()):
+        bad.append(("nt-seam", M, N, K, tile))
+L.vitamd_set_debug(-2147483648)
+for (R, P, Q) in [(4096, 768, 3072), (1000, 512, 768)]:
+    l, r = ints((R, P), -2, 2, 7), ints((R, Q), -2, 2, 8)
+    out = torch.full((P, Q), float("nan"), device=dev)
+    ops.gemm_tn(l.to(dev, BF16), r.to(dev, BF16), out, accumulate=False)
+    if not torch.equal(out.cpu(), l.t() @ r):
+        bad.append(("tn-ring5", R, P, Q))
+L.vitamd_set_debug(0)
 print("experimental checks:", "ok" if not bad else bad)
 sys.exit(1 if bad else 0)
