@@ -7,7 +7,7 @@ from vitamd import lib as _explib; _explib.use_experimental()
 from vitamd import ops
 dev = torch.device("cuda")
 g = torch.Generator(device="cpu").manual_seed(1)
-shapes = ((512, 512, 128), (512, 512, 768), (256 * 40, 768, 768), (256 * 197, 2304, 768), (320 * 30 + 64, 768, 3072), (50432, 3072, 768))
+shapes = ((512, 512, 128), (256 * 40, 768, 768), (256 * 197, 2304, 768), (320 * 30 + 64, 768, 3072))
 for (M, N, K) in shapes:
     a = torch.randint(-2, 3, (M, K), generator=g).to(dev, torch.bfloat16)
     b = torch.randint(-2, 3, (N, K), generator=g).to(dev, torch.bfloat16)
@@ -21,7 +21,7 @@ for (M, N, K) in shapes:
         return (ops.gemm_nt(a, b, ops.EPI_DMUL, aux=fac, colsum=cs, tile=tile), cs)
     for epi in ("nobias", "bias", "gelu", "dmul"):
         ref = [t.float() for t in run(epi, 512)]
-        for tile in ((24,) if epi == "dmul" else (24, 25)):
+        for tile in ((24, 26, 27) if epi == "dmul" else (24, 25, 26, 27, 28, 29)):
             if epi == "dmul" and N % 256: continue
             counts = []
             for rep in range(3):

@@ -346,7 +346,13 @@ int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
   if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
     if (!seam_ok(p)) return VITAMD_ERR_SHAPE;
     if (tile == 24) return launch_seam<EPI, 8>(p, stream, device_cus());
-    if constexpr (EPI != EPI_DGELU) return launch_seam<EPI, 10>(p, stream, device_cus());
+    if (tile == 26) return launch_seam<EPI, 8, 1>(p, stream, device_cus());      // request placement experiments: B request in the matrix section
+    if (tile == 27) return launch_seam<EPI, 8, 2>(p, stream, device_cus());      // A and B requests in the matrix section
+    if constexpr (EPI != EPI_DGELU) {
+      if (tile == 28) return launch_seam<EPI, 10, 1>(p, stream, device_cus());
+      if (tile == 29) return launch_seam<EPI, 10, 2>(p, stream, device_cus());
+      return launch_seam<EPI, 10>(p, stream, device_cus());
+    }
   }
   return VITAMD_ERR_ARG;
 }
@@ -363,7 +369,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   const bool pp_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0;
   constexpr bool tall_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU;
 #ifdef VITAMD_EXPERIMENTAL
-  if (tile == 24 || tile == 25) return dispatch_seam_explicit<EPI>(p, stream, tile);
+  if (tile >= 24 && tile <= 29) return dispatch_seam_explicit<EPI>(p, stream, tile);
   if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) {
     const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
     if (r != -1) return r;
