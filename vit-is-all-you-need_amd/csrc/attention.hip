@@ -172,6 +172,54 @@ __device__ __forceinline__ void store_rows_T_lds_resid(__bf16* __restrict__ g, i
   }
 }
 
+// Same through a 2-KiB image (16 rows per pass, two passes): the 8-wave kernels keep the LDS of a workgroup at 2 x npad x 128 + 8 x 2 KiB,
+// the footprint of the 4-wave ones, so that two workgroups - now 16 waves - still share a CU.
+template <bool RES = false>
+__device__ __forceinline__ void store_rows_T_lds2k(__bf16* __restrict__ g, int ld, int N, int r0, int lane, const f32x16 (&acc)[2], float scale, char* img,
+                                                   const float* __restrict__ xi = nullptr, float* __restrict__ xo = nullptr, int ldx = 0) {
+  const int rr = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    f32x4 r[2][2];
+    if constexpr (RES) {                       // residual loads first: their latency overlaps the LDS round trip
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = (lane >> 3) + 8 * it, pc = lane & 7;
+        const float* px = xi + (size_t)min(r0 + 16 * pass + row, N - 1) * ldx + 8 * (pc ^ (row & 7));
+        r[it][0] = *(const f32x4*)px;
+        r[it][1] = *(const f32x4*)(px + 4);
+      }
+    }
+    if ((rr >> 4) == pass) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          u32x2 o = {pack_bf16x2(acc[dt][4 * u] * scale, acc[dt][4 * u + 1] * scale),
+                     pack_bf16x2(acc[dt][4 * u + 2] * scale, acc[dt][4 * u + 3] * scale)};
+          *(u32x2*)(img + (rr & 15) * 128 + (((4 * dt + u) ^ (rr & 7)) << 4) + h * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = (lane >> 3) + 8 * it, pc = lane & 7;                  // image row 0..15 = query row 16 pass + row
+      const u32x4 v = *(const u32x4*)(img + row * 128 + pc * 16);
+      const int grow = r0 + 16 * pass + row;
+      if (grow < N) {
+        const int col = 8 * (pc ^ (row & 7));
+        *(u32x4*)(g + (size_t)grow * ld + col) = v;
+        if constexpr (RES) {
+          f32x4 o0 = {r[it][0][0] + bf16lo(v[0]), r[it][0][1] + bf16hi(v[0]), r[it][0][2] + bf16lo(v[1]), r[it][0][3] + bf16hi(v[1])};
+          f32x4 o1 = {r[it][1][0] + bf16lo(v[2]), r[it][1][1] + bf16hi(v[2]), r[it][1][2] + bf16lo(v[3]), r[it][1][3] + bf16hi(v[3])};
+          float* po = xo + (size_t)grow * ldx + col;
+          *(f32x4*)po = o0;
+          *(f32x4*)(po + 4) = o1;
+        }
+      }
+    }
+  }
+}
+
 struct AttnArgs {
   const __bf16* qkv;   // [B, N, 3, H, 64]
   __bf16* o;           // fwd out / bwd in  [B, N, H*64]
@@ -419,6 +467,97 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
 #endif
 
 // ------------------------------------------------------------------------------------------ backward, dQ
+// ------------------------------------------------------------------------------------------ forward, 129 <= N <= 256, EIGHT waves (round 3)
+// attn_fwd_small_kernel gives each of its 4 waves up to two 32-row query blocks and is bound by memory round trips at 2 workgroups x 4 waves
+// per CU (section 4.2 of DESIGN.md: one workgroup per CU instead of two costs +43 %).  The LDS footprint, not the registers, sets that occupancy,
+// and K / V are shared by the whole workgroup: with EIGHT waves per workgroup - one query block each - the same LDS carries 16 waves per CU, twice
+// the loads in flight, and a head's latency chain (staging -> S -> softmax -> P.V -> store) is walked once per workgroup instead of twice.
+// Plain attention only (no dropout, mask or fused residual).
+template <int NKT, bool RES>
+__global__ __launch_bounds__(512, 4) void attn_fwd_small8_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int head = blockIdx.x;
+  const int b = head / a.H, hh = head % a.H;
+  const int N = a.N, D3 = 3 * a.H * DH, D = a.H * DH;
+  constexpr int nt = NKT, npad = NKT * 32;
+  char* ktile = smem;
+  char* vtile = smem + npad * 128;
+  char* oimg = smem + 2 * npad * 128 + wave * 2048;
+  const __bf16* qbase = a.qkv + (size_t)b * N * D3 + hh * DH;
+  stage_tile(qbase + D, D3, N, npad, ktile, wave, lane, 8);
+  stage_tile(qbase + 2 * D, D3, N, npad, vtile, wave, lane, 8);
+  const int qb = (wave + head) & 7;            // rotate which waves sit out when the head has fewer than 8 query blocks
+  const bool active = qb < nt;
+  bf16x8 qf[4];
+  load_lane_frags(qbase, D3, N, (active ? qb : 0) * 32, lane, qf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(qf[kk]));
+  __syncthreads();
+  if (!active) return;
+  const float c = a.scale_log2e;
+  const int q0 = qb * 32;
+  const int qrow = q0 + (lane & 31);
+  // ONLINE softmax (one key tile of scores in registers at a time): the register-resident score row of attn_fwd_small_kernel (NKT x 16 registers)
+  // does not fit the 128 registers that 16 waves per CU leave a wave
+  float m = NEG_BIG, l = 0.f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll 1
+  for (int T = 0; T < NKT; ++T) {
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, T, kk, lane), qf[kk], st, 0, 0, 0);
+    if (32 * T + 32 > N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (!(32 * T + acc_row(r, lane) < N)) st[r] = NEG_BIG;
+    }
+    float mt = max16(st);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = fast_exp2((m - mn) * c);        // first tile: exp2(-huge) = 0 on zero accumulators
+    m = mn;
+    const float mc = mn * c;
+    float lt = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pexp = fast_exp2(__builtin_fmaf(st[r], c, -mc));
+      lt += pexp;
+      st[r] = pexp;
+    }
+    l = l * alpha + lt;
+    if (T > 0) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const bf16x8 pf = acc_to_frag(st, sidx);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vtile, T, sidx, dt, lane), pf, oacc[dt], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float mc = m * c;
+  const float inv = 1.0f / l;
+  if constexpr (RES)
+    store_rows_T_lds2k<true>(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg, a.resid_in + (size_t)b * N * D + hh * DH,
+                             a.resid_out + (size_t)b * N * D + hh * DH, D);
+  else
+    store_rows_T_lds2k(a.o + (size_t)b * N * D + hh * DH, D, N, q0, lane, oacc, inv, oimg);
+  if (lane < 32 && qrow < N) a.lse2[((size_t)b * a.H + hh) * N + qrow] = mc + log2f(l);
+}
+
 template <bool DROP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1197,7 +1336,16 @@ static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float
     if (e) return e;
   } else
 #endif
-  if (nkt <= 8) {
+  if (nkt >= 5 && nkt <= 8 && !drop && !causal && !(VITAMD_GDBG & 0x8000)) {      // eight waves, one query block each (dbg bit 15 of experimental builds: off)
+    const int lds = 2 * npad * 128 + 8 * 2048;
+    int e = VITAMD_OK;
+#define FWD_SMALL8(K) case K: \
+      if (a.resid_in) { e = set_lds(attn_fwd_small8_kernel<K, true>, lds); if (!e) hipLaunchKernelGGL((attn_fwd_small8_kernel<K, true>), dim3(B * H), dim3(512), lds, stream, a); } \
+      else { e = set_lds(attn_fwd_small8_kernel<K, false>, lds); if (!e) hipLaunchKernelGGL((attn_fwd_small8_kernel<K, false>), dim3(B * H), dim3(512), lds, stream, a); } break;
+    switch (nkt) { FWD_SMALL8(5) FWD_SMALL8(6) FWD_SMALL8(7) FWD_SMALL8(8) }
+#undef FWD_SMALL8
+    if (e) return e;
+  } else if (nkt <= 8) {
     const int lds = 2 * npad * 128 + 4 * 4096 + ((VITAMD_GDBG & 0x4000) ? 32768 : 0);      // (dbg bit 14, experimental builds: occupancy probe - one workgroup per CU)
     int e = VITAMD_OK;
 #define FWD_SMALL(K) case K: e = drop ? launch_fwd_small<K, true>(a, lds, stream) : launch_fwd_small<K, false>(a, lds, stream); break;
