@@ -466,13 +466,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
 #include "experimental/attention_fwd_persistent.inc"
 #endif
 
-// ------------------------------------------------------------------------------------------ backward, dQ
 // ------------------------------------------------------------------------------------------ forward, 129 <= N <= 256, EIGHT waves (round 3)
-// attn_fwd_small_kernel gives each of its 4 waves up to two 32-row query blocks and is bound by memory round trips at 2 workgroups x 4 waves
-// per CU (section 4.2 of DESIGN.md: one workgroup per CU instead of two costs +43 %).  The LDS footprint, not the registers, sets that occupancy,
-// and K / V are shared by the whole workgroup: with EIGHT waves per workgroup - one query block each - the same LDS carries 16 waves per CU, twice
-// the loads in flight, and a head's latency chain (staging -> S -> softmax -> P.V -> store) is walked once per workgroup instead of twice.
-// Plain attention only (no dropout, mask or fused residual).
+// attn_fwd_small_kernel gives each of its 4 waves up to two 32-row query blocks, needs 229 registers for the register-resident score row and is
+// bound by memory round trips at 2 workgroups x 4 waves per CU (DESIGN.md sections 4.2, 4.4).  Here a workgroup has EIGHT waves - one query block
+// each - that share the staged K / V, and the softmax is ONLINE over a rolled key-tile loop, so a wave needs 102 registers: two workgroups
+// = 16 waves share a CU at the LDS footprint of the 4-wave kernel (2 x npad x 128 + 8 x 2 KiB).  93 against 103 us at B = 256, N = 197, H = 12.
+// Non-causal, no dropout; RES: also writes resid_out = resid_in + bf16(o) (the 4-wave kernel's fused residual form).
+// ------------------------------------------------------------------------------------------
 template <int NKT, bool RES>
 __global__ __launch_bounds__(512, 4) void attn_fwd_small8_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -558,6 +558,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small8_kernel(const AttnArgs 
   if (lane < 32 && qrow < N) a.lse2[((size_t)b * a.H + hh) * N + qrow] = mc + log2f(l);
 }
 
+// ------------------------------------------------------------------------------------------ backward, dQ
 template <bool DROP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -11,6 +11,9 @@
 // The round-1 kernels (pipe / persistent / ring / deep) are measured alternatives in experimental/gemm_nt_variants.inc, built only with
 // `make EXPERIMENTAL=1` (libvitamd_exp.so, for the A/B tools); DESIGN.md section 4 holds their numbers.
 #include <type_traits>
+#include <mutex>
+#include <cmath>
+#include <cstring>
 #include "gemm_nt_epilogue.h"
 
 namespace {
@@ -338,6 +341,57 @@ static bool prefer_tall(const GemmNtArgs& p) {
 
 #include "gemm_nt_seam.h"
 
+// bf16 nearest-even of a double, decided on exact distances (no float intermediate rounding)
+static unsigned short bf16_rne_d(double v) {
+  auto val = [](unsigned short b) { const unsigned w = (unsigned)b << 16; float g; memcpy(&g, &w, 4); return (double)g; };
+  const float f = (float)v;
+  unsigned u;
+  memcpy(&u, &f, 4);
+  unsigned short best = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  double bd = fabs(val(best) - v);
+  const unsigned short first = best;
+  for (int dl = -1; dl <= 1; dl += 2) {
+    const unsigned short n = (unsigned short)(first + dl);
+    const double dd = fabs(val(n) - v);
+    if (dd < bd || (dd == bd && !(n & 1) && (best & 1))) { best = n; bd = dd; }
+  }
+  return best;
+}
+
+// Device image of the erf-GELU table the seam kernel's lookup reads (gemm_nt_seam.h::gelu_lookup8): entry sign x 2048 + (|bits| - 0x3900) for
+// bf16 inputs 2^-13 <= |x| < 8 holds bf16(x Phi(x)) | bf16(Phi(x) + x phi(x)) << 16, from double (erfc for the tail).  One 16-KiB allocation per
+// device, made on first use (never inside a stream capture: the caller then gets null and launches the formula kernels).
+static const unsigned* gelu_table(hipStream_t stream) {
+  static std::mutex mu;
+  static const unsigned* tabs[64] = {};
+  static unsigned host[4096];
+  static bool built = false;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (tabs[dev]) return tabs[dev];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  if (!built) {
+    for (int sg = 0; sg < 2; ++sg)
+      for (int i = 0; i < 2048; ++i) {
+        const unsigned w = (unsigned)(0x3900 + i) << 16;
+        float ax;
+        memcpy(&ax, &w, 4);
+        const double x = sg ? -(double)ax : (double)ax;
+        const double cdf = 0.5 * erfc(-x * 0.70710678118654752440);
+        const double pdf = 0.39894228040143267794 * exp(-0.5 * x * x);
+        host[sg * 2048 + i] = (unsigned)bf16_rne_d(x * cdf) | ((unsigned)bf16_rne_d(cdf + x * pdf) << 16);
+      }
+    built = true;
+  }
+  void* d = nullptr;
+  if (hipMalloc(&d, sizeof(host)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  tabs[dev] = (const unsigned*)d;
+  return tabs[dev];
+}
+
 #ifdef VITAMD_EXPERIMENTAL
 #include "experimental/gemm_nt_variants.inc"
 // tile codes 24 / 25 (experimental builds): the seam kernel (gemm_nt_seam.h) on 256- / 320-row tiles whatever the automatic rule says
@@ -346,6 +400,13 @@ int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
   if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
     if (!seam_ok(p)) return VITAMD_ERR_SHAPE;
     if (tile == 24) return launch_seam<EPI, 8>(p, stream, device_cus());
+    if constexpr (EPI == EPI_GELU) {
+      if (tile == 30) {                                                            // 256-row tiles with the GELU table
+        GemmNtArgs q = p;
+        q.gelu_tab = gelu_table(stream);
+        return launch_seam<EPI, 8, 0, true>(q, stream, device_cus());
+      }
+    }
     if (tile == 26) return launch_seam<EPI, 8, 1>(p, stream, device_cus());      // request placement experiments: B request in the matrix section
     if (tile == 27) return launch_seam<EPI, 8, 2>(p, stream, device_cus());      // A and B requests in the matrix section
     if constexpr (EPI != EPI_DGELU) {
@@ -369,7 +430,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   const bool pp_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0;
   constexpr bool tall_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU;
 #ifdef VITAMD_EXPERIMENTAL
-  if (tile >= 24 && tile <= 29) return dispatch_seam_explicit<EPI>(p, stream, tile);
+  if (tile >= 24 && tile <= 30) return dispatch_seam_explicit<EPI>(p, stream, tile);
   if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) {
     const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
     if (r != -1) return r;
@@ -392,6 +453,15 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
     if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
       if (!no_seam && seam_ok(p) && p.K <= 1536 && !(VITAMD_DBG(p) & 0x20000)) {
         const int cus = device_cus();
+        if constexpr (EPI == EPI_GELU) {
+          // bf16 pre-activations: gelu and gelu' by table (gelu_lookup8) instead of erf / exp / rcp - the 256-row ring leaves the 16 KiB it needs
+          // (dbg bit 20 of experimental builds: the formula kernels)
+          if (big_tiles >= 3L * cus && !(VITAMD_DBG(p) & 0x100000)) {
+            GemmNtArgs q = p;
+            q.gelu_tab = gelu_table(stream);
+            if (q.gelu_tab) return launch_seam<EPI, 8, 0, true>(q, stream, cus);
+          }
+        }
         if constexpr (EPI != EPI_DGELU) {
           if (prefer_tall(p) && (long)((p.M + 319) / 320) * ((p.N + 255) / 256) >= 3L * cus) return launch_seam<EPI, 10>(p, stream, cus);
         }

@@ -72,15 +72,55 @@ struct SeamSchedule {
   }
 };
 
-template <int EPI, int MT, int RQ = 0>
+// erf-GELU by table for bf16 inputs (EPI_GELU on the 256-row seam kernel).  The pre-activation reaches this point rounded to bf16 (autocast's
+// Linear output, transformer.py:37-38), so gelu(x) and gelu'(x) are functions of 16 bits: for 2^-13 <= |x| < 8 (16 exponents x 128 mantissas x 2
+// signs = 4096 inputs) the LDS image holds bf16(gelu(x)) | bf16(gelu'(x)) << 16, correctly rounded from double (gelu_table() in gemm_nt.hip).
+// Per PAIR of elements: 9 packed-16-bit / 32-bit integer operations, two ds_read_b32 and two v_perm against ~41 VALU-equivalents of the
+// erf / exp / rcp formula (two quarter-rate transcendentals per element).  Inputs outside the table (|x| < 2^-13, |x| >= 8, inf, nan: ~1e-4 of
+// N(0,1) data) take the formula - a wave-uniform branch, per element.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_lookup8(const u32x4& v, const char* tab, bool want_dg, u32x4& a, u32x4& d) {
+  constexpr unsigned T_LO = 0x3900u;                 // bf16 bits of 2^-13; the table ends below 0x4100 = 8.0
+  unsigned r[4], any = 0u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned t = v[c] & 0x7fff7fffu;
+    const u16x2 rr = __builtin_bit_cast(u16x2, t) - (u16x2){(unsigned short)T_LO, (unsigned short)T_LO};      // wraps below the table
+    r[c] = __builtin_bit_cast(unsigned, rr);
+    any |= r[c];
+    const u16x2 rc = __builtin_elementwise_min(rr, (u16x2){2047, 2047});
+    // byte offset of entry sign x 2048 + index in each half: plain 32-bit arithmetic (no carry between the halves: index <= 4095).  Written this
+    // way on purpose: with the sign taken by a packed 16-bit shift inside this unrolled loop hipcc 7.2 used pair 0's sign for all four pairs.
+    const unsigned b = (__builtin_bit_cast(unsigned, rc) | ((v[c] >> 4) & 0x08000800u)) << 2;
+    const unsigned elo = *(const unsigned*)(tab + (b & 0xffffu));
+    const unsigned ehi = *(const unsigned*)(tab + (b >> 16));
+    a[c] = __builtin_amdgcn_perm(ehi, elo, 0x05040100u);
+    if (want_dg) d[c] = __builtin_amdgcn_perm(ehi, elo, 0x07060302u);
+  }
+  if (__builtin_amdgcn_ballot_w64((any & 0xf800f800u) != 0u)) {                    // an index >= 2048 in some lane of the wave
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float dlo, dhi;
+      const unsigned g = pack_bf16x2(gelu_fwd_grad(bf16lo(v[c]), dlo), gelu_fwd_grad(bf16hi(v[c]), dhi));
+      const unsigned dg = pack_bf16x2(dlo, dhi);
+      const unsigned m = ((r[c] & 0xf800u) ? 0xffffu : 0u) | ((r[c] & 0xf8000000u) ? 0xffff0000u : 0u);
+      a[c] = (g & m) | (a[c] & ~m);
+      if (want_dg) d[c] = (dg & m) | (d[c] & ~m);
+    }
+  }
+}
+
+template <int EPI, int MT, int RQ = 0, bool TAB = false>
 __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
   static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU, "epilogues without (or with up-front) auxiliary loads");
+  static_assert(!TAB || (EPI == EPI_GELU && MT == 8), "the GELU table needs the 16 KiB that only the 256-row ring leaves");
   constexpr int LA = 4;
   using S = SeamSchedule<MT, LA, RQ>;
   constexpr int NP = S::NP;
   constexpr int BM = 32 * MT, BN = 256, WN = 4, NT = 4;
   constexpr int PART = 8192, ASLOT = NP * PART, BSLOT = 32768, BBASE = 2 * ASLOT, OPS = BBASE + 2 * BSLOT;
-  constexpr int STG = (160 * 1024 - OPS) / 8;       // wave-private staging: 4 KiB (MT = 8) / 2 KiB (MT = 10)
+  constexpr int STG = TAB ? 2048 : (160 * 1024 - OPS) / 8;       // wave-private staging: 4 KiB (MT = 8) / 2 KiB (MT = 10, or MT = 8 with the GELU table behind it)
+  constexpr int TABOFF = OPS + 8 * STG;              // TAB: gelu_table() image, 4096 x 4 B
   constexpr int SL = STG / 2048;                     // 16-row slices staged per round
   static_assert(SL >= 1 && MT % SL == 0, "staging");
   // vector-memory instructions every wave issues per epilogue BEHIND the next tile's requests
@@ -155,6 +195,14 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
   const char* const rdB[2] = {smem + BBASE + wn * 64 * 128 + frag_off, smem + BBASE + wn * 64 * 128 + (frag_off ^ 64)};
 
 #define VITAMD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  if constexpr (TAB) {                               // 16 KiB, once per (persistent) workgroup; visible to every wave after the first barrier below
+    const u32x4* src = (const u32x4*)p.gelu_tab + 2 * tid;
+    const u32x4 t0 = src[0], t1 = src[1];
+    u32x4* dst = (u32x4*)(smem + TABOFF) + 2 * tid;
+    dst[0] = t0;
+    dst[1] = t1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
   int ti = blockIdx.x;
   Tile cur = coords(ti);
   offsets(cur);
@@ -333,12 +381,21 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
             asm_bstore16_nt(v, rsO, voff, soff);
           } else if constexpr (EPI == EPI_GELU) {
             u32x4 a, d = v;
+#ifdef VITAMD_EXPERIMENTAL
+            if (p.dbg & 1) a = v;                                                // timing-only ablation: no erf / exp
+            else
+#endif
+            if constexpr (TAB) gelu_lookup8(v, smem + TABOFF, p.gelu_dg != 0, a, d);
+            else
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               float dlo, dhi;
               a[c] = pack_bf16x2(gelu_fwd_grad(bf16lo(v[c]), dlo), gelu_fwd_grad(bf16hi(v[c]), dhi));
               if (p.gelu_dg) d[c] = pack_bf16x2(dlo, dhi);                       // `out` carries gelu'(pre) for the backward
             }
+#ifdef VITAMD_EXPERIMENTAL
+            if (!(p.dbg & 2))                                                    // timing-only ablation: no second output
+#endif
             asm_bstore16_nt(d, rsO, voff, soff);
             asm_bstore16_nt(a, rsO2, voff, soff);
           } else {
@@ -385,9 +442,10 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
 #undef VITAMD_WAIT_VM
 }
 
-template <int EPI, int MT, int RQ = 0>
+template <int EPI, int MT, int RQ = 0, bool TAB = false>
 int launch_seam(const GemmNtArgs& p, hipStream_t stream, int cus) {
-  auto kern = gemm_nt_seam_kernel<EPI, MT, RQ>;
+  auto kern = gemm_nt_seam_kernel<EPI, MT, RQ, TAB>;
+  if (TAB && !p.gelu_tab) return VITAMD_ERR_ARG;
   if (int e = set_lds(kern, 160 * 1024)) return e;
   const int tiles = ((p.M + 32 * MT - 1) / (32 * MT)) * ((p.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(tiles > cus ? cus : tiles), dim3(512), 160 * 1024, stream, p);

@@ -32,6 +32,7 @@ struct GemmNtArgs {
   // stored-derivative GELU (ABI codes VITAMD_EPI_GELU_DG / VITAMD_EPI_DMUL): EPI_GELU writes out = bf16(gelu'(pre)) instead
   // of pre, EPI_DGELU multiplies by aux as stored instead of evaluating gelu'(aux)
   int gelu_dg;
+  const unsigned* gelu_tab;   // device image of gelu_table() (set by the dispatcher for the table form of the seam kernel, else null)
 };
 
 struct GemmTnArgs {
