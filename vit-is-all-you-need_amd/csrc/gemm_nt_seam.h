@@ -315,7 +315,11 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
         for (int j = 0; j < NT; ++j) pk[i][j] = (u32x2){pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])};
 #pragma unroll
       for (int it = 0; it < 2 * MT; ++it) {
+#ifdef VITAMD_EXPERIMENTAL
+        aux[it] = asm_bload16(srdAux, (mrow0 + 8 * it < p.M && !(p.dbg & 4)) ? obase : OOB, rstep * (unsigned)it);      // (dbg bit 2, timing only: no factor traffic)
+#else
         aux[it] = asm_bload16(srdAux, mrow0 + 8 * it < p.M ? obase : OOB, rstep * (unsigned)it);      // rows >= M: out of range -> 0
+#endif
       }
     } else {
       // the wave's 64 bias values -> the head of its (idle) staging area, by LDS-DMA: nothing lands in a register before the wait below
@@ -334,6 +338,8 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
     constexpr int NREQ = S::prologue_requests();
     // ONE wait statement on every path: the pre-loaded registers are operands, so nothing that reads them can be scheduled above it
     // (two statements in the arms of a branch made hipcc copy the registers - before the data had landed - ahead of one of them)
+    // (dGELU: one wait per ROUND - round 0 starting when 4 of the 16 factor loads are back - was measured equal, 275.6 against 276.6 us: what the
+    // factor loads cost is their issue and their HBM bytes, not the latency of the last of them)
     if constexpr (EPI == EPI_DGELU) {
       static_assert(MT == 8, "16 pre-load registers named in one asm statement");
       asm volatile("s_waitcnt vmcnt(%16)" : "+v"(aux[0]), "+v"(aux[1]), "+v"(aux[2]), "+v"(aux[3]), "+v"(aux[4]), "+v"(aux[5]), "+v"(aux[6]), "+v"(aux[7]), "+v"(aux[8]), "+v"(aux[9]), "+v"(aux[10]), "+v"(aux[11]), "+v"(aux[12]), "+v"(aux[13]), "+v"(aux[14]), "+v"(aux[15]) : "n"(NREQ) : "memory");
@@ -413,22 +419,26 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
         }
       }
     }
+#ifdef VITAMD_EXPERIMENTAL
+    if (EPI == EPI_DGELU && !(p.dbg & 8)) {         // (dbg bit 3, timing only: no column sums)
+#else
     if constexpr (EPI == EPI_DGELU) {
-      // column sums of the stored tile (bias gradient of the producing Linear): per-wave partials -> LDS -> one atomic per column and wave row.
-      // Every wave executes both barriers and exactly one atomic instruction (N % 256 == 0 is a launch condition).
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                    // every wave is done with its staging image
-      float* red = (float*)(smem + OPS);               // [8 waves][8 rsub][64 cols] floats = 16 KiB
-      float* mine = red + (wave * 8 + rsub) * 64 + 8 * (pc ^ rsub);
-      *(f32x4*)mine = (f32x4){cs[0], cs[1], cs[2], cs[3]};
-      *(f32x4*)(mine + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const int c = tid & 255, half = tid >> 8, wnn = c >> 6, cc = c & 63;
-      float s = 0.f;
+#endif
+      // column sums of the stored tile (bias gradient of the producing Linear).  Lanes (rsub, pc) with equal pc ^ rsub hold partial sums of the
+      // same 8 columns (their rows differ): a butterfly over rsub (partner lane ^ 9 b keeps pc ^ rsub) totals them in registers, then lane
+      // (rsub, pc) adds column rsub of its chunk - exactly one atomic instruction per wave (N % 256 == 0 is a launch condition), no barrier and
+      // no LDS image (the round-3 first form went through LDS behind two workgroup barriers: +19 us per dgrad-fc2 launch).
 #pragma unroll
-      for (int r = 0; r < 8; ++r) s += red[((half * 4 + wnn) * 8 + r) * 64 + cc];
-      atomicAdd(p.colsum + n0 + c, s);
+      for (int bf = 1; bf < 8; bf <<= 1)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cs[c] += __shfl_xor(cs[c], 9 * bf, 64);
+      float s = cs[0];
+#pragma unroll
+      for (int c = 1; c < 8; ++c) s = rsub == c ? cs[c] : s;
+#ifdef VITAMD_EXPERIMENTAL
+      if (p.dbg & 16) { if (s == 123.456f) p.colsum[0] = s; } else      // (dbg bit 4, timing only: the butterfly without the atomic)
+#endif
+      atomicAdd(p.colsum + n0 + wn * 64 + 8 * (pc ^ rsub) + rsub, s);
     }
     if (!has_next) break;
     ti = ti_next;
