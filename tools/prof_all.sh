@@ -3,7 +3,6 @@
 # usage (on the GPU box): bash tools/prof_all.sh   -> gpurun_out/r3p/*   (copy what is judged into profiles/r03/)
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3p; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-python3 $R/bench.py --steps 10 --warmup 3 > $O/bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python3 $R/tools/prof_step.py > $O/prof_ss.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
@@ -16,4 +15,7 @@ python3 -c "import json,sys; sys.path.insert(0,'.'); import bench; json.dump({'c
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/final_kernel_stats.csv
 find $O/prof_ss -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/final_single_stream_kernel_stats.csv
 rm -rf $O/prof $O/prof_ss $O/pmc_mfma $O/pmc_hbm
+# the bench line last, against THIS pass's counters (bench.py reads profiles/r03/final_pmc_*: refresh the box's copy first)
+cp $O/final_pmc_mfma.json $O/final_pmc_hbm_traffic.json $O/final_pmc_meta.json $R/profiles/r03/
+python3 $R/bench.py --steps 10 --warmup 3 > $O/bench.log 2>&1
 tail -1 $O/bench.log | cut -c1-160
