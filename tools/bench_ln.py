@@ -2,7 +2,8 @@
 import os, sys, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
-from vitamd import ops
+from vitamd import ops, lib
+if len(sys.argv) > 1 and sys.argv[1] == "sweep": lib.use_experimental()
 dev = torch.device("cuda")
 M, D = 256 * 197, 768
 g = torch.Generator(device="cpu").manual_seed(2)
@@ -23,3 +24,11 @@ for _ in range(1):
         us = statistics.median(t(fn) for _ in range(5))
         print(f"{name:52s} {us:6.1f} us  {M * D * bpe / us / 1e6:.2f} TB/s")
 
+if len(sys.argv) > 1 and sys.argv[1] == "sweep":      # experimental library: block cap of the column-sum form (dbg bits 24-31, units of 256 blocks)
+    import ctypes
+    from vitamd import lib
+    L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
+    fn = cases["same + column sums of the bf16 copy"][0]
+    for cap in (1, 2, 3, 4, 6, 8, 12, 16, 32, 64):
+        L.vitamd_set_debug(cap << 24); us = statistics.median(t(fn) for _ in range(5)); L.vitamd_set_debug(0)
+        print(f"column-sum form, at most {256 * cap:5d} blocks: {us:6.1f} us")

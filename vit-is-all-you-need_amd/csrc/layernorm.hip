@@ -187,7 +187,10 @@ __global__ __launch_bounds__(256) void ln_bwd_generic(const __bf16* __restrict__
 // launch, tools/bench_ln.py); the column-sum form keeps a grid-stride loop - every workgroup ends with D atomics (12 608 of them: 312 us).
 int grid_for(int M, bool colsum = false) {
   int blocks = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  const int cap = !colsum ? 16384 : 1024;           // column-sum form: 2048 -> 118 us, 1024 -> 111, 512 -> 110, 4096 -> 135
+  int cap = !colsum ? 16384 : 1024;                 // column-sum form: 2048 -> 118 us, 1024 -> 111, 512 -> 110, 4096 -> 135
+#ifdef VITAMD_EXPERIMENTAL
+  if (colsum && (g_vitamd_debug >> 24)) cap = 256 * (g_vitamd_debug >> 24);     // dbg bits 24-31: the cap in units of 256 blocks (sweep)
+#endif
   return blocks < cap ? blocks : cap;
 }
 
