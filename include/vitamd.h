@@ -66,9 +66,12 @@ int vitamd_gemm_tn_bf16(const void* L, const void* Rm, float* out, int R, int P,
 
 /* Same GEMM with a caller-provided split-K workspace (>= splits * ceil(P/256) * ceil(Q/256) * 256 KiB,
  * vitamd_gemm_tn_ws_bytes tells): partial tiles are written with plain stores and summed by a second
- * pass (bitwise reproducible, ~4x the rate of the atomic form).  accumulate = 0 overwrites `out`. */
+ * pass (bitwise reproducible, ~4x the rate of the atomic form).  accumulate = 0 overwrites `out`.
+ * `form` picks the kernel (same results): which one is faster depends on what runs beside the launch. */
+#define VITAMD_TN_FORM_SHARED 0    /* 8 waves per workgroup, 2/3 of the register file: waves of other kernels (LayerNorm) can share the CU */
+#define VITAMD_TN_FORM_EXCLUSIVE 1 /* 12 waves (4 of them only issue the LDS-DMA requests): 15 % faster alone, fills the CU; bit-identical */
 int vitamd_gemm_tn_bf16_ws(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
-                           int splits, float* ws, long ws_bytes, int accumulate, void* stream);
+                           int splits, float* ws, long ws_bytes, int accumulate, int form, void* stream);
 long vitamd_gemm_tn_ws_bytes(int R, int P, int Q, int splits);
 
 /* ---- LayerNorm (no affine, eps as given) on the fp32 residual stream -------------------------

@@ -3,7 +3,7 @@
 #include "vitamd_internal.h"
 #include "../../include/vitamd.h"
 
-extern "C" int vitamd_abi_version(void) { return 6; }
+extern "C" int vitamd_abi_version(void) { return 7; }
 
 #ifdef VITAMD_EXPERIMENTAL
 int g_vitamd_debug = 0;
@@ -35,13 +35,14 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
 
 extern "C" int vitamd_gemm_tn_bf16(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
                                    int splits, void* stream) {
-  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits, nullptr, 0, 1};
+  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits, nullptr, 0, 1, 0};
   return vitamd_gemm_tn_impl(a, (hipStream_t)stream);
 }
 
 extern "C" int vitamd_gemm_tn_bf16_ws(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,
-                                      int splits, float* ws, long ws_bytes, int accumulate, void* stream) {
-  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits, ws, (size_t)(ws_bytes < 0 ? 0 : ws_bytes), accumulate};
+                                      int splits, float* ws, long ws_bytes, int accumulate, int form, void* stream) {
+  if (form != 0 && form != 1) return VITAMD_ERR_ARG;
+  GemmTnArgs a{L, Rm, out, R, P, Q, ldl, ldr, ldo, splits, ws, (size_t)(ws_bytes < 0 ? 0 : ws_bytes), accumulate, form};
   return vitamd_gemm_tn_impl(a, (hipStream_t)stream);
 }
 

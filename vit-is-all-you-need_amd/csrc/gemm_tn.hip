@@ -191,6 +191,133 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_pp_kernel(const GemmTnArgs a,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Loader-wave form of gemm_tn_pp_kernel (round 3; GemmTnArgs::form = 1): the same ring, phases and MFMA order (bit-identical results), but the
+// LDS-DMA requests move out of the eight compute waves into FOUR loader waves (waves 8-11, one per SIMD).  A compute wave's read section is then
+// the 12 transposed reads alone; in gemm_tn_pp_kernel it also issues 2 DMA pieces whose issue costs 60-185 cycles each beside the partner wave's
+// 256 cycles of MFMAs.  Loader l issues the four pieces the compute waves l (L operand) and l + 4 (R operand) would have issued, waits for them
+// with the same counted vmcnt arithmetic (4 pieces per quarter instead of 2) and takes part in every barrier on the first wave row's timeline.
+// 12 waves x 168 registers = 3 x 168 per SIMD lane: fits the 512-register file only because this kernel needs <= 168 - and fills it: nothing
+// can share the CU with such a workgroup, where the 8-wave form leaves 176 registers per lane for e.g. LayerNorm waves of the other stream.
+// Measured (tools/bench_tn.py, profiles/r03/tn_loader_waves.log): alone 171 / 214 / 216 us against 201 / 247 / 258 for the three ViT-B weight
+// gradients (-15 %); inside the step it wins where the launch runs beside kernels that fill their CUs anyway (the fc2 weight gradient, beside
+// the two input-gradient GEMMs: -0.1 ... -0.36 ms per step) and loses where the 8-wave form shared CUs with LayerNorm (all launches: +0.46 ms).
+template <int NQ, int D>
+__global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
+  static_assert(D >= 2 && D <= NQ - 2, "prefetch distance: WAR rule");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NW;
+  const int ntile = tiles_p * tiles_q;
+  const int id = xcd_remap(blockIdx.x, ntile * splits);
+  const int split = id / ntile, tile = id % ntile;
+  const int p0 = (tile / tiles_q) * BP, q0 = (tile % tiles_q) * BQ;
+  const int nsteps = (a.R + BR - 1) / BR;
+  const int s_lo = (int)((long)nsteps * split / splits), s_hi = (int)((long)nsteps * (split + 1) / splits);
+  if (s_lo >= s_hi) return;
+  const int g_lo = 4 * s_lo, g_hi = 4 * s_hi;
+#define VITAMD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  if (loader) {
+    const int l = wave - NW;                         // pieces of compute-wave identities (wave & 3) == l, both operands
+    const srd_t srdL = make_srd(a.L, (size_t)a.R * a.ldl * 2), srdR = make_srd(a.Rm, (size_t)a.R * a.ldr * 2);
+    unsigned voffL[2], voffR[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (l * 2 + i) * 2 + (lane >> 5);
+      const int logical = (lane & 31) ^ ((row & 3) << 2);
+      voffL[i] = (p0 + logical * 8 < a.P) ? (unsigned)(((size_t)row * a.ldl + p0 + logical * 8) * 2) : 0x80000000u;
+      voffR[i] = (q0 + logical * 8 < a.Q) ? (unsigned)(((size_t)row * a.ldr + q0 + logical * 8) * 2) : 0x80000000u;
+    }
+    const unsigned qbL = (unsigned)16 * a.ldl * 2, qbR = (unsigned)16 * a.ldr * 2;
+    const unsigned dstL = lds_addr(smem) + l * 2048, dstR = dstL + 8192;
+    unsigned soL = (unsigned)g_lo * qbL, soR = (unsigned)g_lo * qbR;
+    int slot_w = 0;
+    auto issue = [&]() {
+      const unsigned o = slot_w * QSLOT;
+      asm_glds16(srdL, dstL + o, voffL[0], soL);
+      asm_glds16(srdL, dstL + o + 1024, voffL[1], soL);
+      asm_glds16(srdR, dstR + o, voffR[0], soR);
+      asm_glds16(srdR, dstR + o + 1024, voffR[1], soR);
+      soL += qbL; soR += qbR;
+      slot_w = slot_w + 1 == NQ ? 0 : slot_w + 1;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue();
+    VITAMD_WAIT_VM(4 * (D - 1));
+    __builtin_amdgcn_s_barrier();
+    for (int g = g_lo; g < g_hi; ++g) {
+      issue();
+      VITAMD_WAIT_VM(4 * (D - 1));                  // quarter g + 1 has landed
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();                   // the first wave row's balancing barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  const int wp = wave / WQ, wq = wave % WQ;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int h = lane >> 5, colhalf = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int rowpart = (8 * h + qq) * 512 + (pp & 1) * 8;
+  int offA[MT], offB[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int chunk = (wp * (BP / WP) + i * 32) / 8 + 2 * colhalf + (pp >> 1);
+    offA[i] = rowpart + ((chunk ^ (qq << 2)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int chunk = (wq * (BQ / WQ) + j * 32) / 8 + 2 * colhalf + (pp >> 1);
+    offB[j] = 8192 + rowpart + ((chunk ^ (qq << 2)) << 4);
+  }
+  __builtin_amdgcn_s_barrier();                     // quarter g_lo has landed (the loaders waited for it)
+  asm volatile("" ::: "memory");
+  if (wp == 1) __builtin_amdgcn_s_barrier();
+  int slot_r = 0;
+  for (int g = g_lo; g < g_hi; ++g) {
+    const char* q = smem + slot_r * QSLOT;
+    bf16x8 af[MT], bfr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = tr_frag(q + offB[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = tr_frag(q + offA[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    slot_r = slot_r + 1 == NQ ? 0 : slot_r + 1;
+  }
+  if (wp == 0) __builtin_amdgcn_s_barrier();
+#undef VITAMD_WAIT_VM
+  float* wt = a.ws + ((size_t)split * ntile + tile) * (BP * BQ);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ql = wq * (BQ / WQ) + j * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int pl = wp * (BP / WP) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wt[(pl + (r & 3) + 8 * (r >> 2)) * BQ + ql] = acc[i][j][r];
+    }
+  }
+}
+
 #ifdef VITAMD_EXPERIMENTAL
 #include "experimental/gemm_tn_variants.inc"
 #endif
@@ -291,8 +418,19 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   }
 #endif
   if (use_ws) {
+    bool loader = a.form == 1;
+#ifdef VITAMD_EXPERIMENTAL
+    // A/B: bit 23 = the loader-wave form for every launch; bits 20 / 21 / 22 = where P <= 768 (fc2), P = 2304 (QKV), P = 3072 (fc1); bit 19 = never
+    loader = !(g_vitamd_debug & 0x80000) && (loader || (g_vitamd_debug & 0x800000) || ((g_vitamd_debug & 0x100000) && a.P <= 768) ||
+                                             ((g_vitamd_debug & 0x200000) && a.P == 2304) || ((g_vitamd_debug & 0x400000) && a.P == 3072));
+#endif
+    if (loader) {
+      if (int e = set_lds(gemm_tn_ld_kernel<8, 4>, lds)) return e;
+      hipLaunchKernelGGL((gemm_tn_ld_kernel<8, 4>), grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
+    } else {
     if (int e = set_lds(gemm_tn_pp_kernel<true, 8, 4>, lds)) return e;
     hipLaunchKernelGGL((gemm_tn_pp_kernel<true, 8, 4>), grid, block, lds, stream, a, tiles_p, tiles_q, splits);
+    }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits,
                        a.accumulate);
   } else {

@@ -44,6 +44,7 @@ struct GemmTnArgs {
   float* ws;       // optional split-K workspace: [splits][tiles][256][256] fp32 partial tiles (plain stores) + reduce pass
   size_t ws_bytes;
   int accumulate;  // with a workspace: 1 = out += sum, 0 = out = sum (no pre-zeroing needed)
+  int form;        // with a workspace: 0 = 8-wave ping-pong kernel, 1 = 12-wave loader form (VITAMD_TN_FORM_*)
 };
 
 int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream);

@@ -113,6 +113,21 @@ ATTN_FUSED_RESID = False  # A/B knob: x1 = x0 + attention written by the attenti
 TN_TARGET_WGS = None   # None = follow the NT launch form (252 beside persistent NT launches, 128 beside one workgroup per tile), read on every call; an int overrides.  Workgroups per layer weight-gradient GEMM (tiles x split-K factor); 0 = the kernel's own rule (~256 = every CU).  Whole-step A/B (tools/ab_splits.py) with the PERSISTENT NT launches: 96 -> 31.21 ms, 128 -> 30.86, 160 -> 30.79, 192 -> 30.55, 216 -> 30.44, 252 -> 30.3, 288 -> 31.0, 504 -> 31.8 (with one NT workgroup per tile the optimum was 128-144: 31.45 vs 32.26 at 252)
 
 
+TN_FORM_POLICY = "auto"   # which weight-gradient kernel (ops.TN_FORM_*; same results).  "auto": the 12-wave EXCLUSIVE form for the fc2 weight gradient -
+# launched at the start of a layer's backward, beside the two input-gradient GEMMs of the MLP, whose workgroups fill their CUs anyway - and for every weight
+# gradient when there is no second stream; the 8-wave SHARED form elsewhere (the fc1 / QKV weight gradients run beside LayerNorm backward, whose waves share
+# CUs with it).  Whole-step A/B (tools/ab_dbg.py, profiles/r03/ab_tn_loader_*.log): fc2 only -0.10 / -0.36 ms on two boxes; all three +0.46 ms; fc1 or QKV
+# alone +0.26 / +0.29; without the second stream all three -0.62 ms.  "shared" / "exclusive" force one form.
+
+
+def _tn_form(which):
+    if TN_FORM_POLICY == "shared":
+        return ops.TN_FORM_SHARED
+    if TN_FORM_POLICY == "exclusive" or not SIDE.enabled:
+        return ops.TN_FORM_EXCLUSIVE
+    return ops.TN_FORM_EXCLUSIVE if which == "fc2" else ops.TN_FORM_SHARED
+
+
 def _tn_splits(dW):
     """Split-K factor for a weight-gradient GEMM that runs on the side stream BESIDE the input-gradient chain: a little under one
     workgroup per CU (180 of 256) - fewer, longer workgroups write fewer fp32 partial tiles for the reduce pass, and the CUs they
@@ -374,25 +389,25 @@ def layer_backward(g2, saved, wqkv, w1, w2, B, N, H, causal, grads, dy2=None, ha
         dy2 = ops.cast_bf16_dropout(g2, drop[2:]) if drop[2] > 0 else ops.cast_bf16(g2)
     # ---- MLP
     def wgrad_fc2():
-        ops.gemm_tn(dy2, h, dW2, accumulate=False, splits=_tn_splits(dW2))
+        ops.gemm_tn(dy2, h, dW2, accumulate=False, splits=_tn_splits(dW2), form=_tn_form("fc2"))
         if not have_db2:
             ops.colsum(dy2, db2)
     if SIDE_POLICY == 0:
         on_side(wgrad_fc2, dy2, h, dW2, db2)
     dpre = ops.gemm_nt(dy2, w2_t, ops.EPI_DMUL if GELU_STORED_GRAD else ops.EPI_DGELU, aux=pre, colsum=db1)   # dgrad fc2 . gelu'
     if SIDE_POLICY == 0:
-        on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1)), dpre, bln, dW1)
+        on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1), form=_tn_form("fc1")), dpre, bln, dW1)
     if SIDE_POLICY == 2:
         on_side(wgrad_fc2, dy2, h, dW2, db2)
     dbln = ops.gemm_nt(dpre, w1_t, ops.EPI_BIAS_BF16)                            # dgrad fc1
     if SIDE_POLICY == 1:
         on_side(wgrad_fc2, dy2, h, dW2, db2)
     if SIDE_POLICY in (1, 2):
-        on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1)), dpre, bln, dW1)
+        on_side(lambda: ops.gemm_tn(dpre, bln, dW1, accumulate=False, splits=_tn_splits(dW1), form=_tn_form("fc1")), dpre, bln, dW1)
     g1, d_o = ops.layernorm_bwd(dbln, x1, mean2, rstd2, g_res=g2, want_bf16=True, xhat=bln if LN_BWD_XHAT else None)
     # ---- attention
     dqkv = ops.attention_bwd(qkv, o, lse, d_o, B, N, H, causal, dbias=dbqkv, dropout=drop[:2])   # also adds the QKV bias gradient
-    on_side(lambda: ops.gemm_tn(dqkv, a, dWqkv, accumulate=False, splits=_tn_splits(dWqkv)), dqkv, a, dWqkv)
+    on_side(lambda: ops.gemm_tn(dqkv, a, dWqkv, accumulate=False, splits=_tn_splits(dWqkv), form=_tn_form("qkv")), dqkv, a, dWqkv)
     da = ops.gemm_nt(dqkv, wqkv_t, ops.EPI_BIAS_BF16)                            # dgrad qkv
     g0, g0b = ops.layernorm_bwd(da, x0, mean1, rstd1, g_res=g1, want_bf16=emit_bf16, colsum=emit_colsum, dropout=emit_dropout,
                                 xhat=a if LN_BWD_XHAT else None)

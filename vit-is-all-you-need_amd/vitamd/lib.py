@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitamd.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c = ctypes
 _P, _I, _F, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_ulonglong
@@ -22,7 +22,7 @@ SIGNATURES = {
     "vitamd_abi_version": [],
     "vitamd_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vitamd_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "vitamd_gemm_tn_bf16_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P],
+    "vitamd_gemm_tn_bf16_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P],
     "vitamd_gemm_tn_ws_bytes": [_I, _I, _I, _I],
     "vitamd_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "vitamd_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -125,9 +125,14 @@ def _workspace(device, nbytes):
     return ws
 
 
-def gemm_tn(l, r, out, splits=0, accumulate=True, atomic=False):
+TN_FORM_SHARED, TN_FORM_EXCLUSIVE = 0, 1      # include/vitamd.h VITAMD_TN_FORM_*
+
+
+def gemm_tn(l, r, out, splits=0, accumulate=True, atomic=False, form=TN_FORM_SHARED):
     """out[P,Q] (fp32) (+)= l[R,P]^T @ r[R,Q].  Split-K partials go through a workspace + reduce
-    pass (reproducible) unless atomic=True (fp32 atomics straight into `out`, accumulate only)."""
+    pass (reproducible) unless atomic=True (fp32 atomics straight into `out`, accumulate only).
+    form: TN_FORM_SHARED (8-wave workgroups that leave room on the CU for another stream's LayerNorm waves) or TN_FORM_EXCLUSIVE (12 waves,
+    four of them dedicated to the LDS-DMA requests: 15 % faster alone, fills the CU); bit-identical results."""
     _need(l, BF16, "l", 2); _need(r, BF16, "r", 2); _need(out, F32, "out", 2)
     R, P = l.shape
     R2, Q = r.shape
@@ -141,7 +146,7 @@ def gemm_tn(l, r, out, splits=0, accumulate=True, atomic=False):
         nbytes = _L().vitamd_gemm_tn_ws_bytes(R, P, Q, splits)
         ws = _workspace(l.device, nbytes)
         code = _L().vitamd_gemm_tn_bf16_ws(_p(l), _p(r), _p(out), R, P, Q, P, Q, Q, splits, _p(ws), ws.numel() * 4, int(accumulate),
-                                           _stream())
+                                           int(form), _stream())
     _lib.check(code, f"gemm_tn[R={R},P={P},Q={Q}]")
     return out
 
