@@ -45,7 +45,8 @@ def _timed(fns, reps):
 def kernel_roofline(dev):
     """Live HIP-event timing of the two dominant kernels at the shapes one training step launches them with:
       gemm_nt_pp_kernel - every forward Linear and every input-gradient GEMM (6 launches per layer, ~2/3 of the step's FLOPs),
-      gemm_tn_pp_kernel - every weight-gradient GEMM (3 launches per layer, split-K reduce pass included).
+      gemm_tn_pp_kernel / gemm_tn_ld_kernel - every weight-gradient GEMM (3 launches per layer, split-K reduce pass included; the form each
+      launch takes in the step: functions._tn_form).
     achieved = algorithmic FLOPs (2*M*N*K per launch) / average launch duration over the launches of one layer, timed in the order
     the layer issues them.  `roofline` itself describes the NT family (the larger share); `kernels` carries both."""
     from vitamd import ops, functions as F
@@ -71,9 +72,9 @@ def kernel_roofline(dev):
     ]
     dWqkv, dW1, dW2 = (torch.empty(s, device=dev) for s in ((3 * D, D), (4 * D, D), (D, 4 * D)))
     tn_calls = [       # split-K factors as the step chooses them (vitamd.functions._tn_splits)
-        ("dW_fc2", lambda: ops.gemm_tn(x1, x4, dW2, accumulate=False, splits=F._tn_splits(dW2)), 2.0 * M * D * 4 * D),
-        ("dW_fc1", lambda: ops.gemm_tn(x4, x1, dW1, accumulate=False, splits=F._tn_splits(dW1)), 2.0 * M * D * 4 * D),
-        ("dW_qkv", lambda: ops.gemm_tn(x3, x1, dWqkv, accumulate=False, splits=F._tn_splits(dWqkv)), 2.0 * M * D * 3 * D),
+        ("dW_fc2", lambda: ops.gemm_tn(x1, x4, dW2, accumulate=False, splits=F._tn_splits(dW2), form=F._tn_form("fc2")), 2.0 * M * D * 4 * D),
+        ("dW_fc1", lambda: ops.gemm_tn(x4, x1, dW1, accumulate=False, splits=F._tn_splits(dW1), form=F._tn_form("fc1")), 2.0 * M * D * 4 * D),
+        ("dW_qkv", lambda: ops.gemm_tn(x3, x1, dWqkv, accumulate=False, splits=F._tn_splits(dWqkv), form=F._tn_form("qkv")), 2.0 * M * D * 3 * D),
     ]
     prof = pmc_profile()
 
@@ -87,7 +88,7 @@ def kernel_roofline(dev):
                 "recorded_mfma_util": (prof.get("mfma_util") or {}).get(kernel), "recorded_traffic": (prof.get("traffic") or {}).get(kernel)}
 
     nt = family(nt_calls, "gemm_nt")          # gemm_nt_pp_kernel and its seam form gemm_nt_seam_kernel
-    tn = family(tn_calls, "gemm_tn_pp_kernel")
+    tn = family(tn_calls, "gemm_tn")          # gemm_tn_pp_kernel (8 waves) and gemm_tn_ld_kernel (12 waves, loader waves)
     # (informational) the same weight-gradient GEMMs cut for the whole chip (252 workgroups) instead of the ~128 the step uses so that
     # they leave half the CUs to the main stream's kernels
     full = [(n, (lambda l=l, r=r, o=o: ops.gemm_tn(l, r, o, accumulate=False, splits=0)), f) for (n, _, f), (l, r, o) in
@@ -102,7 +103,7 @@ def kernel_roofline(dev):
            "traffic": (nt["recorded_traffic"] or {}).get("bytes_per_launch") if rec_ok else None,
            "recorded": {"static": True, "stale": bool(prof.get("stale")), "source": prof.get("source"), "made_at": prof.get("meta"),
                         "traffic_detail": nt["recorded_traffic"], "mfma_util": nt["recorded_mfma_util"]},
-           "per_shape_tflops": nt["per_shape_tflops"], "kernels": {"gemm_nt": nt, "gemm_tn_pp_kernel": tn}}
+           "per_shape_tflops": nt["per_shape_tflops"], "kernels": {"gemm_nt": nt, "gemm_tn": tn}}
     return out
 
 
@@ -134,8 +135,8 @@ def pmc_profile():
     try:
         mf = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_mfma.json")))
         util = {}
-        for fam in ("gemm_nt", "gemm_tn_pp_kernel"):
-            sel = {k: v for k, v in mf.items() if (("gemm_nt_pp_kernel" in k or "gemm_nt_seam_kernel" in k) if fam == "gemm_nt" else fam in k) and v["avg_us_profiled"] > 50}
+        for fam in ("gemm_nt", "gemm_tn"):
+            sel = {k: v for k, v in mf.items() if (("gemm_nt_pp_kernel" in k or "gemm_nt_seam_kernel" in k) if fam == "gemm_nt" else ("gemm_tn_pp_kernel" in k or "gemm_tn_ld_kernel" in k)) and v["avg_us_profiled"] > 50}
             rows = [(v["launches"], v["avg_us_profiled"], v["mfma_util"]) for v in sel.values()]
             if rows:       # time-weighted over the family's launches
                 util[fam] = {"mfma_busy_frac": round(sum(n * t * u for n, t, u in rows) / sum(n * t for n, t, _ in rows), 4),
@@ -152,10 +153,10 @@ def pmc_profile():
             tot_n = sum(v["launches"] for v in nt)
             mb = sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in nt) / tot_n
             traffic["gemm_nt"] = {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int(NT_ALGO_MB * 1e6)}
-        tn = [v for k, v in tr.items() if "gemm_tn_pp_kernel<" in k]
+        tn = [v for k, v in tr.items() if "gemm_tn_pp_kernel<" in k or "gemm_tn_ld_kernel<" in k]
         if tn:
             tot_n = sum(v["launches"] for v in tn)
-            traffic["gemm_tn_pp_kernel"] = {"bytes_per_launch": int(sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in tn) / tot_n * 1e6),
+            traffic["gemm_tn"] = {"bytes_per_launch": int(sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in tn) / tot_n * 1e6),
                                             "algorithmic_bytes_per_launch": int((387 + 387 + 309) / 3 * 1e6 + 9.4e6)}
         out["traffic"] = traffic
     except Exception:
