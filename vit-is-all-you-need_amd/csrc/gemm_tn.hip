@@ -425,8 +425,23 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
                                              ((g_vitamd_debug & 0x200000) && a.P == 2304) || ((g_vitamd_debug & 0x400000) && a.P == 3072));
 #endif
     if (loader) {
+#ifdef VITAMD_EXPERIMENTAL
+      const int dv = (g_vitamd_debug >> 16) & 7;     // bits 16-18: ring / prefetch-distance variants of the loader form (A/B)
+      if (dv >= 6) {
+        auto kern = dv == 6 ? gemm_tn_ldv_kernel<8, 4> : gemm_tn_ldv_kernel<8, 6>;
+        if (int e = set_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
+      } else if (dv) {
+        auto kern = dv == 1 ? gemm_tn_ld_kernel<8, 6> : dv == 2 ? gemm_tn_ld_kernel<10, 4> : dv == 3 ? gemm_tn_ld_kernel<10, 6> : gemm_tn_ld_kernel<10, 8>;
+        const int l2 = (dv >= 2 && dv <= 4 ? 10 : 8) * QSLOT;
+        if (int e = set_lds(kern, l2)) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(768), l2, stream, a, tiles_p, tiles_q, splits);
+      } else
+#endif
+      {
       if (int e = set_lds(gemm_tn_ld_kernel<8, 4>, lds)) return e;
       hipLaunchKernelGGL((gemm_tn_ld_kernel<8, 4>), grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
+      }
     } else {
     if (int e = set_lds(gemm_tn_pp_kernel<true, 8, 4>, lds)) return e;
     hipLaunchKernelGGL((gemm_tn_pp_kernel<true, 8, 4>), grid, block, lds, stream, a, tiles_p, tiles_q, splits);
