@@ -376,6 +376,14 @@ extern "C" long vitamd_gemm_tn_ws_bytes(int R, int P, int Q, int splits) {
   if (vitamd_gemm_tn_wide_ok(R, P, Q, splits)) return (long)vitamd_gemm_tn_wide_splits(R, P, Q) * P * Q * (long)sizeof(float);
 #endif
   const long ntile = (long)((P + BP - 1) / BP) * ((Q + BQ - 1) / BQ);
+#ifdef VITAMD_EXPERIMENTAL
+  if (g_vitamd_debug & 0x20000000) {                 // room for the 384-row tiles split factor (bit 29)
+    const int nt384 = ((P + 383) / 384) * ((Q + BQ - 1) / BQ);
+    int s384 = 252 / nt384; if (s384 < 1) s384 = 1;
+    const int s = auto_splits(R, P, Q, splits);
+    return (long)(s384 > s ? s384 : s) * ntile * BP * BQ * (long)sizeof(float);
+  }
+#endif
   return (long)auto_splits(R, P, Q, splits) * ntile * BP * BQ * (long)sizeof(float);
 }
 
@@ -426,6 +434,16 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
 #endif
     if (loader) {
 #ifdef VITAMD_EXPERIMENTAL
+      if (g_vitamd_debug & 0x20000000) {             // bit 29: 384 x 256 tiles on twelve compute waves (gemm_tn_x12_kernel); needs the workspace of vitamd_gemm_tn_ws_bytes under the same bit
+        const int tp384 = (a.P + 383) / 384, nt384 = tp384 * tiles_q;
+        int s384 = 252 / nt384; if (s384 < 1) s384 = 1;
+        const int nsteps = (a.R + BR - 1) / BR; if (s384 > nsteps) s384 = nsteps;
+        if (a.ws_bytes < (size_t)s384 * ntile * BP * BQ * sizeof(float)) return VITAMD_ERR_ARG;
+        if (int e = set_lds(gemm_tn_x12_kernel<8, 4>, 8 * 20480)) return e;
+        hipLaunchKernelGGL((gemm_tn_x12_kernel<8, 4>), dim3(nt384 * s384), dim3(768), 8 * 20480, stream, a, tp384, tiles_q, s384, tiles_p);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, s384, a.accumulate);
+        return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+      }
       const int dv = (g_vitamd_debug >> 16) & 7;     // bits 16-18: ring / prefetch-distance variants of the loader form (A/B)
       if (dv >= 6) {
         auto kern = dv == 6 ? gemm_tn_ldv_kernel<8, 4> : gemm_tn_ldv_kernel<8, 6>;
