@@ -445,8 +445,8 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
       }
       const int dv = (g_vitamd_debug >> 16) & 7;     // bits 16-18: ring / prefetch-distance variants of the loader form (A/B)
-      if (dv >= 6) {
-        auto kern = dv == 6 ? gemm_tn_ldv_kernel<8, 4> : gemm_tn_ldv_kernel<8, 6>;
+      if (dv >= 5) {
+        auto kern = dv == 5 ? gemm_tn_lda_kernel<8> : dv == 6 ? gemm_tn_ldv_kernel<8, 4> : gemm_tn_ldv_kernel<8, 6>;
         if (int e = set_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
       } else if (dv) {
