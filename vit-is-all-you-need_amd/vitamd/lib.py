@@ -95,6 +95,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VitamdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the HIP kernels are the only implementation of this path; there is no fallback)")
+    # torch FIRST: its wheel bundles its own HIP runtime (libamdhip64.so of the ROCm it was built against).  Loaded before torch, libvitamd.so would pull
+    # /opt/rocm's copy in and torch then its own: two HIP runtimes in one process - kernels registered with one, streams and pointers from the other -
+    # and the first launch fails (seen on a GPU box with `build(); smoke()` in one process).  With torch imported first the library's libamdhip64
+    # dependency resolves to the runtime already in the process.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     if LIB_PATH == EXP_LIB_PATH:
         lib.vitamd_set_debug.argtypes = [ctypes.c_int]
