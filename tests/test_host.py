@@ -22,6 +22,29 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(dll, name), name
     assert lib.load().vitamd_abi_version() == lib.ABI_VERSION
+    # ... with as many parameters in the binding as in the header (a dropped or added argument would shift every later one silently)
+    for name, params in re.findall(r"\b(?:int|long)\s+(vitamd_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.S):
+        n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        assert n == len(lib.SIGNATURES[name]), (name, n, len(lib.SIGNATURES[name]))
+
+
+def test_weight_gradient_form_policy():
+    """functions.TN_FORM_POLICY: "auto" = the 12-wave exclusive kernel for the fc2 weight gradient (beside GEMMs that fill their CUs anyway) and for
+    every weight gradient when there is no second stream; the 8-wave shared kernel where LayerNorm waves share the CUs."""
+    from vitamd import functions as F, ops
+    keep_p, keep_s = F.TN_FORM_POLICY, F.SIDE.enabled
+    try:
+        F.TN_FORM_POLICY, F.SIDE.enabled = "auto", True
+        assert [F._tn_form(w) for w in ("fc2", "fc1", "qkv")] == [ops.TN_FORM_EXCLUSIVE, ops.TN_FORM_SHARED, ops.TN_FORM_SHARED]
+        F.SIDE.enabled = False
+        assert {F._tn_form(w) for w in ("fc2", "fc1", "qkv")} == {ops.TN_FORM_EXCLUSIVE}
+        F.SIDE.enabled = True
+        F.TN_FORM_POLICY = "shared"
+        assert {F._tn_form(w) for w in ("fc2", "fc1", "qkv")} == {ops.TN_FORM_SHARED}
+        F.TN_FORM_POLICY = "exclusive"
+        assert {F._tn_form(w) for w in ("fc2", "fc1", "qkv")} == {ops.TN_FORM_EXCLUSIVE}
+    finally:
+        F.TN_FORM_POLICY, F.SIDE.enabled = keep_p, keep_s
 
 
 def test_state_dict_contract_matches_reference_keys_and_shapes():
