@@ -104,8 +104,8 @@ def kernel_roofline(dev):
            "recorded": {"static": True, "stale": bool(prof.get("stale")), "source": prof.get("source"), "made_at": prof.get("meta"),
                         "traffic_detail": nt["recorded_traffic"], "mfma_util": nt["recorded_mfma_util"]},
            "per_shape_tflops": nt["per_shape_tflops"], "kernels": {"gemm_nt": nt, "gemm_tn": tn},
-           # what actually caps these main loops: a CU is fed ~17 B per clock from L2 (one LDS-DMA piece of 1 KiB per ~60
-           # cycles), a 256x256 (320x256) tile needs 32 (28.8) B per clock at full MFMA rate
+           # what these main loops are observed to get: ~17 B per clock per CU of operand fill (one 1-KiB LDS-DMA piece per ~60
+           # cycles; the bare path does 52-58 from L2), where a 256x256 (320x256) tile needs 32 (28.8) B per clock at full MFMA rate
            "feed_ceiling": {"bytes_per_clk_per_cu": 17, "frac_of_mfma_peak": {"256x256": 0.53, "320x256": 0.59}, "source": "DESIGN.md 4.6, profiles/r03/tn_loader_ring_variants.log"}}
     return out
 

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_pp_kernel(const GemmTnArgs a,
 // Measured (tools/bench_tn.py, profiles/r03/tn_loader_waves.log): alone 171 / 214 / 216 us against 201 / 247 / 258 for the three ViT-B weight
 // gradients (-15 %); inside the step it wins where the launch runs beside kernels that fill their CUs anyway (the fc2 weight gradient, beside
 // the two input-gradient GEMMs: -0.1 ... -0.36 ms per step) and loses where the 8-wave form shared CUs with LayerNorm (all launches: +0.46 ms).
-template <int NQ, int D>
+template <int NQ, int D, int ABL = 0>      // ABL (experimental builds, timing only, results are garbage): 1 = no MFMAs, 2 = no transposed LDS reads, 3 = neither
 __global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
   static_assert(D >= 2 && D <= NQ - 2, "prefetch distance: WAR rule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -248,8 +248,10 @@ __global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int
     __builtin_amdgcn_s_barrier();
     for (int g = g_lo; g < g_hi; ++g) {
       issue();
-      VITAMD_WAIT_VM(4 * (D - 1));                  // quarter g + 1 has landed
       __builtin_amdgcn_s_barrier();
+      // quarter g + 1 is first read by the first wave row BEHIND the second barrier of this iteration, so the wait may sit here rather than in
+      // front of the first barrier (one more interval for the requests to land).  Measured equal (164 / 212 / 215 us either way).
+      VITAMD_WAIT_VM(4 * (D - 1));
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_s_barrier();                   // the first wave row's balancing barrier
@@ -285,9 +287,9 @@ __global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int
     const char* q = smem + slot_r * QSLOT;
     bf16x8 af[MT], bfr[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bfr[j] = tr_frag(q + offB[j]);
+    for (int j = 0; j < NT; ++j) { if (ABL & 2) { for (int e = 0; e < 8; ++e) bfr[j][e] = (__bf16)1.0f; asm volatile("" : "+v"(bfr[j])); } else bfr[j] = tr_frag(q + offB[j]); }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[i] = tr_frag(q + offA[i]);
+    for (int i = 0; i < MT; ++i) { if (ABL & 2) { for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)1.0f; asm volatile("" : "+v"(af[i])); } else af[i] = tr_frag(q + offA[i]); }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) { if (ABL & 1) { acc[i][j][0] += (float)af[i][0] * (float)bfr[j][0]; } else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -450,8 +452,9 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
         if (int e = set_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
       } else if (dv) {
-        auto kern = dv == 1 ? gemm_tn_ld_kernel<8, 6> : dv == 2 ? gemm_tn_ld_kernel<10, 4> : dv == 3 ? gemm_tn_ld_kernel<10, 6> : gemm_tn_ld_kernel<10, 8>;
-        const int l2 = (dv >= 2 && dv <= 4 ? 10 : 8) * QSLOT;
+        // 1-3: timing-only ablations of the loader form (no MFMAs / no transposed reads / neither); 4: ten-slot ring, 8 quarters ahead
+        auto kern = dv == 1 ? gemm_tn_ld_kernel<8, 4, 1> : dv == 2 ? gemm_tn_ld_kernel<8, 4, 2> : dv == 3 ? gemm_tn_ld_kernel<8, 4, 3> : gemm_tn_ld_kernel<10, 8>;
+        const int l2 = (dv == 4 ? 10 : 8) * QSLOT;
         if (int e = set_lds(kern, l2)) return e;
         hipLaunchKernelGGL(kern, grid, dim3(768), l2, stream, a, tiles_p, tiles_q, splits);
       } else
