@@ -22,16 +22,20 @@ __device__ __forceinline__ void glds16(srd_t srd, unsigned lds_dst, unsigned vof
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
-template <int MODE, int G>      // MODE 0: LDS-DMA, 1: registers;  G pieces in flight per wave
+template <int MODE, int G>      // MODE 0: LDS-DMA, 1: registers, 2: LDS-DMA with GEMM-shaped pieces (two 512-B row segments, rows `share`-strided: see main);  G pieces in flight per wave
 __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t region, int iters, unsigned long long* cycles, unsigned* sink, int share) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   // share > 1: the workgroups b, b + 8, ... of one XCD (round-robin dispatch) read the SAME region in groups of `share`, as GEMM tiles share operand panels
-  const char* mine = src + (size_t)(share > 1 ? (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / share) : blockIdx.x) * region;
+  const char* mine = MODE == 2 ? src + (size_t)(blockIdx.x / 36 % 7) * region : src + (size_t)(share > 1 ? (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / share) : blockIdx.x) * region;
   const srd_t srd = make_srd(mine, region);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + wave * (G * 1024);
   const unsigned step = nw * 1024;                       // the workgroup's waves interleave 1-KiB pieces
   unsigned off = wave * 1024 + lane * 16, acc = 0;
+  // MODE 2: the region is a row-major matrix with rows of 6144 B (a [R x 3072] bf16 operand); this workgroup's panel = 512 B of every row (column block
+  // blockIdx.x % 12), a piece = rows r, r + 1 of the panel, the workgroup's waves walk down the rows
+  const unsigned rowb = 6144u;
+  if (MODE == 2) off = (unsigned)(blockIdx.x % 12) * 512u + (unsigned)(2 * wave + (lane >> 5)) * rowb + (lane & 31) * 16;
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
   u32x4 r[G];
@@ -40,12 +44,12 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t regi
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (MODE == 0) glds16(srd, lds0 + g * 1024, off, 0u);
+      if (MODE == 0 || MODE == 2) glds16(srd, lds0 + g * 1024, off, 0u);
       else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[g]) : "v"(off), "s"(srd) : "memory");
-      off += step;
-      if (off >= region) off -= (unsigned)region;
+      if (MODE == 2) { off += 2 * nw * rowb; if (off >= region) off -= (unsigned)region; }
+      else { off += step; if (off >= region) off -= (unsigned)region; }
     }
-    if (MODE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G / 2) : "memory");      // keep half of them in flight
+    if (MODE != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G / 2) : "memory");      // keep half of them in flight
     else {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G / 2) : "memory");
 #pragma unroll
@@ -138,6 +142,10 @@ int main() {
   // operand panels shared inside an XCD, streamed once (16 MiB per group): what a split-K weight-gradient tile row / column does
   for (int share : {1, 4, 12, 32}) run(fill_kernel<0, 16>, 4, (size_t)16 << 20, 16, "LDS-DMA", share);
   for (int share : {4, 12, 32}) run(fill_kernel<0, 16>, 4, (size_t)4 << 20, 16, "LDS-DMA", share);
+  // GEMM-shaped: 7 row ranges (split-K) x 36 tiles; every workgroup streams the 512-B column block (blockIdx % 12) of its range's rows, two rows per piece:
+  // panels shared by the 3 workgroups with equal blockIdx % 12 in a range, ranges of 48 MiB (8 192 rows x 6 144 B)
+  run(fill_kernel<2, 16>, 4, (size_t)48 << 20, 16, "DMA-strided");
+  run(fill_kernel<2, 8>, 8, (size_t)48 << 20, 8, "DMA-strided");
   run(fill_kernel<0, 16>, 4, (size_t)64 << 10, 16, "LDS-DMA");
   run(fill_kernel<0, 16>, 4, (size_t)16 << 20, 16, "LDS-DMA");
   for (int cw : {0, 4, 8}) {
