@@ -27,15 +27,19 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t regi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   // share > 1: the workgroups b, b + 8, ... of one XCD (round-robin dispatch) read the SAME region in groups of `share`, as GEMM tiles share operand panels
-  const char* mine = MODE == 2 ? src + (size_t)(blockIdx.x / 36 % 7) * region : src + (size_t)(share > 1 ? (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / share) : blockIdx.x) * region;
+  const char* mine = MODE == 2 ? src + (size_t)((((unsigned)share >> 28 & 1) ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x) / 36 % 7) * region : src + (size_t)(share > 1 ? (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / share) : blockIdx.x) * region;
   const srd_t srd = make_srd(mine, region);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + wave * (G * 1024);
   const unsigned step = nw * 1024;                       // the workgroup's waves interleave 1-KiB pieces
   unsigned off = wave * 1024 + lane * 16, acc = 0;
   // MODE 2: the region is a row-major matrix with rows of 6144 B (a [R x 3072] bf16 operand); this workgroup's panel = 512 B of every row (column block
   // blockIdx.x % 12), a piece = rows r, r + 1 of the panel, the workgroup's waves walk down the rows
-  const unsigned rowb = 6144u;
-  if (MODE == 2) off = (unsigned)(blockIdx.x % 12) * 512u + (unsigned)(2 * wave + (lane >> 5)) * rowb + (lane & 31) * 16;
+  // geometry packed in `share` for MODE 2: bits 0-15 row bytes, bits 16-27 panel width in bytes (512: a piece = 2 rows, 1024: a piece = 1 row, 256: 4 rows), bit 28: co-locate
+  const unsigned rowb = MODE == 2 ? (unsigned)share & 0xffffu : 6144u, panelw = MODE == 2 ? ((unsigned)share >> 16) & 0xfffu : 512u;
+  const unsigned ncb = rowb / panelw, rpp = 1024u / panelw;          // column blocks per row, rows per piece
+  unsigned wg = blockIdx.x;
+  if (MODE == 2 && ((unsigned)share >> 28 & 1)) { const unsigned q = gridDim.x >> 3, x = wg & 7; wg = x * q + (wg >> 3); }      // consecutive ids share an XCD (round-robin dispatch)
+  if (MODE == 2) off = (wg % ncb) * panelw + (rpp * wave + lane / (panelw / 16)) * rowb + (lane % (panelw / 16)) * 16;
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
   u32x4 r[G];
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t regi
     for (int g = 0; g < G; ++g) {
       if (MODE == 0 || MODE == 2) glds16(srd, lds0 + g * 1024, off, 0u);
       else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[g]) : "v"(off), "s"(srd) : "memory");
-      if (MODE == 2) { off += 2 * nw * rowb; if (off >= region) off -= (unsigned)region; }
+      if (MODE == 2) { off += rpp * nw * rowb; if (off >= region) off -= (unsigned)region; }
       else { off += step; if (off >= region) off -= (unsigned)region; }
     }
     if (MODE != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G / 2) : "memory");      // keep half of them in flight
@@ -144,8 +148,15 @@ int main() {
   for (int share : {4, 12, 32}) run(fill_kernel<0, 16>, 4, (size_t)4 << 20, 16, "LDS-DMA", share);
   // GEMM-shaped: 7 row ranges (split-K) x 36 tiles; every workgroup streams the 512-B column block (blockIdx % 12) of its range's rows, two rows per piece:
   // panels shared by the 3 workgroups with equal blockIdx % 12 in a range, ranges of 48 MiB (8 192 rows x 6 144 B)
-  run(fill_kernel<2, 16>, 4, (size_t)48 << 20, 16, "DMA-strided");
-  run(fill_kernel<2, 8>, 8, (size_t)48 << 20, 8, "DMA-strided");
+  // rows of 6144 B (R-like: 12 column blocks of 512 B, 3 sharers) / 1536 B (L-like: 3 column blocks, 12 sharers); pieces of 2 rows x 512 B, 1 row x 1 KiB, 4 rows x 256 B
+  for (int coloc : {0, 1})
+    for (unsigned rowb : {6144u, 1536u})
+      for (unsigned pw : {512u, 1024u, 256u}) {
+        if (rowb % pw) continue;
+        const int geo = (int)(rowb | (pw << 16) | ((unsigned)coloc << 28));
+        printf("rows of %u B, panel %u B, sharers co-located %d:  ", rowb, pw, coloc);
+        run(fill_kernel<2, 16>, 4, (size_t)rowb * 8192, 16, "DMA-geom", geo);
+      }
   run(fill_kernel<0, 16>, 4, (size_t)64 << 10, 16, "LDS-DMA");
   run(fill_kernel<0, 16>, 4, (size_t)16 << 20, 16, "LDS-DMA");
   for (int cw : {0, 4, 8}) {
