@@ -203,12 +203,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmNtArgs p) {
   }
   const unsigned lds0 = lds_addr(smem) + wave * 1024;
   constexpr unsigned OOB = 0x80000000u;
+  // (experimental builds, timing only, results garbage: dbg bit 28 = every request out of range - the instruction is issued, nothing is fetched;
+  //  dbg bit 24 = no request instructions at all: what the main loop costs without its feed)
   auto request_a = [&](int kt, int j) {
-    const bool live = kt >= 0 && kt < nkt;
+    const bool live = kt >= 0 && kt < nkt && !(VITAMD_DBG(p) & 0x10000000);
+    if (VITAMD_DBG(p) & 0x1000000) return;
     asm_glds16(srdA, lds0 + (kt & 1) * BUFB + j * PART, live ? voffA[j] : OOB, live ? (unsigned)kt * 128u : 0u);
   };
   auto request_b = [&](int kt, int q) {
-    const bool live = kt >= 0 && kt < nkt;
+    const bool live = kt >= 0 && kt < nkt && !(VITAMD_DBG(p) & 0x10000000);
+    if (VITAMD_DBG(p) & 0x1000000) return;
     asm_glds16(srdB, lds0 + (kt & 1) * BUFB + NP * PART + q * 8192, live ? voffB[q] : OOB, live ? (unsigned)kt * 128u : 0u);
   };
 
