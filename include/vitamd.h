@@ -9,10 +9,14 @@
  * Conventions
  *   - All pointers are DEVICE pointers (HBM), row-major, 16-byte aligned.  "bf16" buffers are
  *     passed as void*; fp32 buffers as float*.
- *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls only enqueue work:
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every entry point except vitamd_init only enqueues work:
  *     no allocation, no synchronisation, safe under HIP-graph capture.
+ *   - vitamd_init(device, stream) is called once per device before the first GEMM with a GELU epilogue: it is the ONLY function that
+ *     allocates (one 16-KiB table image per device) and synchronises.  A GELU launch on a device without it returns VITAMD_ERR_INIT.
  *   - Every function returns VITAMD_OK (0) or a VITAMD_ERR_* code and launches nothing on error.
  *   - The caller owns all memory.  Kernels never allocate.
+ *   - ONE HIP runtime per process: load this library after the framework that owns the streams and pointers you pass in (PyTorch bundles
+ *     its own libamdhip64; a second copy pulled in by an earlier dlopen of this library fails the first launch) - see INTEGRATION.md.
  */
 #ifndef VITAMD_H
 #define VITAMD_H
@@ -25,9 +29,15 @@ extern "C" {
 #define VITAMD_ERR_SHAPE 1   /* unsupported / inconsistent dimensions */
 #define VITAMD_ERR_ARG 2     /* missing pointer or bad enum */
 #define VITAMD_ERR_LAUNCH 3  /* HIP reported a launch error */
+#define VITAMD_ERR_INIT 4    /* vitamd_init has not run for the current device (GELU epilogues need its table) */
 
 /* ABI version of this header (bumped on any signature change). */
 int vitamd_abi_version(void);
+
+/* Per-device set-up, once per device and process (idempotent; device < 0 = the current device; never inside a stream capture): builds the
+ * 4 096-entry table {bf16(gelu(x)), bf16(gelu'(x))} of every bf16 input 2^-13 <= |x| < 8, correctly rounded from float64, that all GELU
+ * epilogues read (replaces the erf of nn.GELU(), transformer.py:38, exactly).  The only entry point that allocates or synchronises. */
+int vitamd_init(int device, void* stream);
 
 /* ---- Linear layers: C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation (MFMA) ------
  * epilogue selectors (argument `epi`):                                                          */
@@ -46,11 +56,24 @@ int vitamd_abi_version(void);
  * one workgroup per tile.  Auto launches problems with more tiles than CUs PERSISTENT (one workgroup per CU walking a strided tile
  * list: faster next to a second stream's kernels, but sensitive to CUs held by other long-running kernels, e.g. collectives; with a
  * short reduction dim (K <= 1536) and >= 3 tiles per CU in the form that requests the next tile's operands before the epilogue);
- * 512 = auto without persistent launches; 1024 = auto with persistent launches but without the seam form.
+ * 512 = auto without persistent launches; 1024 = auto with persistent launches but without the seam / loader forms; 2048 = the
+ * loader-wave form (256-row tiles, twelve waves per workgroup, four of them only issue the operand requests; bias / GELU / dGELU-multiply
+ * epilogues, K % 128 == 0; VITAMD_ERR_SHAPE where it does not apply).  All forms give bit-identical results.
  * Forward of nn.Linear (x W^T + b): A = x, B = W.  Input gradient (dy W): A = dy, B = W^T. */
 int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
                         float* colsum, int M, int N, int K, int ldo, int epi, int n_patches, int seq, int extra,
                         int tile, void* stream);
+
+/* Which kernel the call above would launch for these arguments on the current device (nothing is launched, no pointer is needed):
+ * VITAMD_NT_FORM_* | tile rows << 8, | VITAMD_NT_FORM_TAIL_SPLIT when the launch is cut into a head of whole rounds in that form and a
+ * tail on 128x128 tiles; a negative value is -VITAMD_ERR_*. */
+#define VITAMD_NT_FORM_SMALL 1          /* 128x128 tiles, 4 waves */
+#define VITAMD_NT_FORM_PP 2             /* ping-pong kernel, one workgroup per tile */
+#define VITAMD_NT_FORM_PP_PERSISTENT 3  /* ping-pong kernel, one workgroup per CU walking a tile list */
+#define VITAMD_NT_FORM_SEAM 4           /* persistent, the next tile's fill requested before the epilogue */
+#define VITAMD_NT_FORM_LOADER 5         /* persistent, 8 compute waves + 4 loader waves */
+#define VITAMD_NT_FORM_TAIL_SPLIT 0x80
+int vitamd_gemm_nt_plan(int M, int N, int K, int ldo, int epi, int tile);
 
 /* fc2 with dropout: out f32 = resid + dropout_p(bf16(A.B^T + bias)), mask = hash(seed, row*N+col).
  * replaces transformer.py:39-40,44 (Linear + nn.Dropout(p) + residual add) in training mode.  `tile` as for vitamd_gemm_nt_bf16. */

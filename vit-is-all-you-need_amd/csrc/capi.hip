@@ -3,7 +3,10 @@
 #include "vitamd_internal.h"
 #include "../../include/vitamd.h"
 
-extern "C" int vitamd_abi_version(void) { return 7; }
+extern "C" int vitamd_abi_version(void) { return 8; }
+
+// Per-device set-up: the only entry point that allocates (16 KiB: the erf-GELU table) or synchronises.  Idempotent; device < 0 = the current device.
+extern "C" int vitamd_init(int device, void* stream) { return vitamd_init_impl(device, (hipStream_t)stream); }
 
 #ifdef VITAMD_EXPERIMENTAL
 int g_vitamd_debug = 0;
@@ -25,12 +28,23 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
   if (epi == 6) epi = EPI_GELU;
   if (epi == 7) epi = EPI_DGELU;
   GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, VITAMD_GDBG, 0u, 1.0f, 0u, 0u, 0, dg};
-  #ifdef VITAMD_EXPERIMENTAL
-  if (!(tile >= 0 && tile <= 30) && tile != 128 && tile != 256 && tile != 257 && tile != 320 && tile != 512 && tile != 1024) return VITAMD_ERR_ARG;
+#ifdef VITAMD_EXPERIMENTAL
+  if (!(tile >= 0 && tile <= 30) && tile != 128 && tile != 256 && tile != 257 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) return VITAMD_ERR_ARG;
 #else
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024) return VITAMD_ERR_ARG;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) return VITAMD_ERR_ARG;
 #endif
   return vitamd_gemm_nt_impl(p, (hipStream_t)stream);
+}
+
+// Which kernel the call above would launch on the current device (no launch, no pointer is read): see include/vitamd.h VITAMD_NT_FORM_*.
+extern "C" int vitamd_gemm_nt_plan(int M, int N, int K, int ldo, int epi, int tile) {
+  const int dg = (epi == 6 || epi == 7) ? 1 : 0;
+  if (epi == 6) epi = EPI_GELU;
+  if (epi == 7) epi = EPI_DGELU;
+  static char dummy[16];                   // the launch rules only ask whether the optional pointers are present
+  GemmNtArgs p{dummy, dummy, dummy, dummy, nullptr, dummy, (float*)dummy, M, N, K, ldo, epi, 1, 1, 0, tile, VITAMD_GDBG, 0u, 1.0f, 0u, 0u, 0, dg};
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) return -VITAMD_ERR_ARG;
+  return vitamd_gemm_nt_plan_impl(p);
 }
 
 extern "C" int vitamd_gemm_tn_bf16(const void* L, const void* Rm, float* out, int R, int P, int Q, int ldl, int ldr, int ldo,

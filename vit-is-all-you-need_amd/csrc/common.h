@@ -28,6 +28,7 @@ extern int g_vitamd_debug;
 #define VITAMD_ERR_SHAPE 1
 #define VITAMD_ERR_ARG 2
 #define VITAMD_ERR_LAUNCH 3
+#define VITAMD_ERR_INIT 4
 
 // fp32 -> bf16 round-to-nearest-even (plain cast: hipcc emits v_cvt_pk_bf16_f32, NaN-safe)
 __device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }

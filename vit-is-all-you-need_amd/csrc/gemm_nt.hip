@@ -12,6 +12,7 @@
 // `make EXPERIMENTAL=1` (libvitamd_exp.so, for the A/B tools); DESIGN.md section 4 holds their numbers.
 #include <type_traits>
 #include <mutex>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include "gemm_nt_epilogue.h"
@@ -344,6 +345,7 @@ static bool prefer_tall(const GemmNtArgs& p) {
 }
 
 #include "gemm_nt_seam.h"
+#include "gemm_nt_ld.h"
 
 // bf16 nearest-even of a double, decided on exact distances (no float intermediate rounding)
 static unsigned short bf16_rne_d(double v) {
@@ -362,20 +364,31 @@ static unsigned short bf16_rne_d(double v) {
   return best;
 }
 
-// Device image of the erf-GELU table the seam kernel's lookup reads (gemm_nt_seam.h::gelu_lookup8): entry sign x 2048 + (|bits| - 0x3900) for
+// Device image of the erf-GELU table every GELU epilogue reads (gemm_nt_epilogue.h::gelu_lookup): entry sign x 2048 + (|bits| - 0x3900) for
 // bf16 inputs 2^-13 <= |x| < 8 holds bf16(x Phi(x)) | bf16(Phi(x) + x phi(x)) << 16, from double (erfc for the tail).  One 16-KiB allocation per
-// device, made on first use (never inside a stream capture: the caller then gets null and launches the formula kernels).
-static const unsigned* gelu_table(hipStream_t stream) {
+// device, made by vitamd_init - the ONLY place this library allocates or synchronises; the launch functions read the pointer and nothing else.
+static std::atomic<const unsigned*> g_gelu_tab[64];
+
+static const unsigned* gelu_table() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+  return g_gelu_tab[dev].load(std::memory_order_acquire);
+}
+
+}  // namespace
+
+int vitamd_init_impl(int device, hipStream_t stream) {
   static std::mutex mu;
-  static const unsigned* tabs[64] = {};
   static unsigned host[4096];
   static bool built = false;
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return VITAMD_ERR_LAUNCH; }
+  if (device < 0) device = cur;
+  if (device >= 64) return VITAMD_ERR_ARG;
   std::lock_guard<std::mutex> lock(mu);
-  if (tabs[dev]) return tabs[dev];
+  if (g_gelu_tab[device].load(std::memory_order_acquire)) return VITAMD_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return VITAMD_ERR_ARG; }   // never inside a capture
   if (!built) {
     for (int sg = 0; sg < 2; ++sg)
       for (int i = 0; i < 2048; ++i) {
@@ -389,12 +402,21 @@ static const unsigned* gelu_table(hipStream_t stream) {
       }
     built = true;
   }
+  if (device != cur && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return VITAMD_ERR_ARG; }
   void* d = nullptr;
-  if (hipMalloc(&d, sizeof(host)) != hipSuccess) return nullptr;
-  if (hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-  tabs[dev] = (const unsigned*)d;
-  return tabs[dev];
+  bool ok = hipMalloc(&d, sizeof(host)) == hipSuccess;
+  ok = ok && hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();                // a failed HIP call must not surface as a later launch's error
+    if (d) (void)hipFree(d);
+  }
+  if (device != cur) (void)hipSetDevice(cur);
+  if (!ok) return VITAMD_ERR_LAUNCH;
+  g_gelu_tab[device].store((const unsigned*)d, std::memory_order_release);
+  return VITAMD_OK;
 }
+
+namespace {
 
 #ifdef VITAMD_EXPERIMENTAL
 #include "experimental/gemm_nt_variants.inc"
@@ -405,11 +427,7 @@ int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
     if (!seam_ok(p)) return VITAMD_ERR_SHAPE;
     if (tile == 24) return launch_seam<EPI, 8>(p, stream, device_cus());
     if constexpr (EPI == EPI_GELU) {
-      if (tile == 30) {                                                            // 256-row tiles with the GELU table
-        GemmNtArgs q = p;
-        q.gelu_tab = gelu_table(stream);
-        return launch_seam<EPI, 8, 0, true>(q, stream, device_cus());
-      }
+      if (tile == 30) return launch_seam<EPI, 8, 0, true>(p, stream, device_cus());          // 256-row tiles with the GELU table
     }
     if (tile == 26) return launch_seam<EPI, 8, 1>(p, stream, device_cus());      // request placement experiments: B request in the matrix section
     if (tile == 27) return launch_seam<EPI, 8, 2>(p, stream, device_cus());      // A and B requests in the matrix section
@@ -423,68 +441,97 @@ int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
 }
 #endif
 
-template <int EPI>
-int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
-  // tile selector of the C ABI: 0 = auto, 128 = the 128x128 kernel, 256 / 320 = the ping-pong kernel on 256- / 320-row tiles
-  // (experimental builds: further codes select the measured alternatives, see experimental/gemm_nt_variants.inc)
+// ---- which kernel a launch takes (one place: the dispatcher below executes the plan, vitamd_gemm_nt_plan reports it) -------------------------
+// tile selector of the C ABI: 0 = auto, 128 = the 128x128 kernel, 256 / 320 = the ping-pong kernel on 256- / 320-row tiles, one workgroup per
+// tile; 512 = auto without persistent launches; 1024 = auto with persistent launches but without the seam form; 2048 = the loader-wave form.
+enum NtForm { NT_FORM_SMALL = 1, NT_FORM_PP = 2, NT_FORM_PP_PERSISTENT = 3, NT_FORM_SEAM = 4, NT_FORM_LOADER = 5 };
+struct NtPlan { int form, rows, err; };
+
+// The loader-wave form (gemm_nt_ld.h) in the automatic choice: see LD_AUTO in DESIGN.md section 4.7 for the measurements behind the rule.
+static bool ld_auto(const GemmNtArgs& p, long big_tiles, int cus) {
+  (void)p; (void)big_tiles; (void)cus;
+  return false;
+}
+
+static NtPlan plan_single(const GemmNtArgs& p) {
   int tile = p.tile;
-  const bool no_seam = tile == 1024;      // ABI code 1024: the automatic choice with persistent launches but WITHOUT the seam form (A/B and start-up probe: ops.seam_probe)
+  const int epi = p.epi;
+  const bool seam_epi = epi == EPI_BIAS_BF16 || epi == EPI_GELU || epi == EPI_DGELU;
+  const bool tall_epi = seam_epi || epi == EPI_RESID_F32;
+  if (tile == 2048) return (seam_epi && ld_ok(p)) ? NtPlan{NT_FORM_LOADER, 256, VITAMD_OK} : NtPlan{0, 0, VITAMD_ERR_SHAPE};
+  const bool no_seam = tile == 1024;      // ABI code 1024: the automatic choice with persistent launches but WITHOUT the seam / loader forms (A/B and start-up probe: ops.seam_probe)
   if (no_seam) tile = 0;
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool pp_ok = (size_t)p.M * p.K * 2 < 0xf0000000ull && (size_t)p.N * p.K * 2 < 0xf0000000ull && p.K % 64 == 0;
-  constexpr bool tall_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU || EPI == EPI_DGELU;
-#ifdef VITAMD_EXPERIMENTAL
-  if (tile >= 24 && tile <= 30) return dispatch_seam_explicit<EPI>(p, stream, tile);
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512) {
-    const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
-    if (r != -1) return r;
-    if (tile == 7) tile = 256;
-    else if (tile == 8) tile = 320;
-    else return VITAMD_ERR_ARG;
-  }
-  if (tile == 0 && (VITAMD_DBG(p) & 0x40000000)) return dispatch_variant<EPI>(p, stream, 2, prefer_tall(p));   // dbg bit 30: the round-1 pipe kernel
-#endif
+  const bool big = p.N >= 256 && big_tiles >= 192 && pp_ok;
+  const bool tall = tall_epi && prefer_tall(p);
   // Automatic choice, more tiles than CUs: the PERSISTENT form (one workgroup per CU walking a strided tile list; same kernel, same
   // results).  Alone it is as fast as one workgroup per tile; inside the training step, next to the weight-gradient GEMMs of the
   // second stream, it is faster: -0.45 / -0.04 / -0.34 / -0.45 ms per step on four boxes (tools/ab_persistent.py).  The explicit
   // tile codes 256 / 320 keep the one-workgroup-per-tile launch.  (dbg bit 5 of experimental builds: no persistent launches)
-  if (tile == 512) tile = 0;      // ABI code 512: the automatic choice WITHOUT persistent launches (one workgroup per tile)
-  else if (tile == 0 && p.N >= 256 && big_tiles >= 192 && pp_ok && !(VITAMD_DBG(p) & 0x20)) {
+  if (tile == 512) tile = 0;              // ABI code 512: the automatic choice WITHOUT persistent launches (one workgroup per tile)
+  else if (tile == 0 && big && !(VITAMD_DBG(p) & 0x20)) {
+    const int cus = device_cus();
     // Short K loops with several tiles per CU: the SEAM form of the persistent kernel (gemm_nt_seam.h: the next tile's pipeline fill is requested
     // before the epilogue, the epilogue runs beside the operand buffers).  Measured on the ViT-B launches (tools/bench_seam.py): QKV 172 -> 163 us,
-    // fc1+GELU 316 -> 298, dgrad-fc2 298 -> 268 (K = 768, 7-10 tiles per CU); equal or 4 % slower where a CU sees only two tiles of a long K loop
-    // (dgrad-fc1 K = 3072, dgrad-QKV K = 2304), which therefore stay on the form below.  Bit-identical results.  (dbg bit 17: off)
-    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
-      if (!no_seam && seam_ok(p) && p.K <= 1536 && !(VITAMD_DBG(p) & 0x20000)) {
-        const int cus = device_cus();
-        if constexpr (EPI == EPI_GELU) {
-          // bf16 pre-activations: gelu and gelu' by table (gelu_lookup8) instead of erf / exp / rcp - the 256-row ring leaves the 16 KiB it needs
-          // (dbg bit 20 of experimental builds: the formula kernels)
-          if (big_tiles >= 3L * cus && !(VITAMD_DBG(p) & 0x100000)) {
-            GemmNtArgs q = p;
-            q.gelu_tab = gelu_table(stream);
-            if (q.gelu_tab) return launch_seam<EPI, 8, 0, true>(q, stream, cus);
-          }
-        }
-        if constexpr (EPI != EPI_DGELU) {
-          if (prefer_tall(p) && (long)((p.M + 319) / 320) * ((p.N + 255) / 256) >= 3L * cus) return launch_seam<EPI, 10>(p, stream, cus);
-        }
-        if (big_tiles >= 3L * cus) return launch_seam<EPI, 8>(p, stream, cus);
+    // fc1+GELU 316 -> 298 (265-276 with the GELU table, which needs the 256-row ring), dgrad-fc2 298 -> 268 (K = 768, 7-10 tiles per CU); equal or
+    // 4 % slower where a CU sees only two tiles of a long K loop (dgrad-fc1 K = 3072, dgrad-QKV K = 2304), which therefore stay on the form
+    // below.  Bit-identical results.  (dbg bit 17: off)
+    if (seam_epi && !no_seam && seam_ok(p)) {
+      if (ld_ok(p) && ld_auto(p, big_tiles, cus)) return NtPlan{NT_FORM_LOADER, 256, VITAMD_OK};
+      if (p.K <= 1536 && !(VITAMD_DBG(p) & 0x20000)) {
+        if (epi == EPI_BIAS_BF16 && tall && (long)((p.M + 319) / 320) * ((p.N + 255) / 256) >= 3L * cus) return NtPlan{NT_FORM_SEAM, 320, VITAMD_OK};
+        if (big_tiles >= 3L * cus) return NtPlan{NT_FORM_SEAM, 256, VITAMD_OK};
       }
     }
-    if constexpr (tall_epi) {
-      if (prefer_tall(p)) return launch_pp<EPI, 10, 4, 6, true>(p, stream);
+    return NtPlan{NT_FORM_PP_PERSISTENT, tall ? 320 : 256, VITAMD_OK};
+  }
+  if (tile == 0) tile = big ? (tall ? 320 : 256) : 128;
+  if (tile == 320) return (tall_epi && pp_ok) ? NtPlan{NT_FORM_PP, 320, VITAMD_OK} : NtPlan{0, 0, VITAMD_ERR_SHAPE};
+  if (tile == 256) return pp_ok ? NtPlan{NT_FORM_PP, 256, VITAMD_OK} : NtPlan{0, 0, VITAMD_ERR_SHAPE};
+  if (tile != 128) return NtPlan{0, 0, VITAMD_ERR_ARG};
+  return p.K % BK == 0 ? NtPlan{NT_FORM_SMALL, 128, VITAMD_OK} : NtPlan{0, 0, VITAMD_ERR_SHAPE};
+}
+
+template <int EPI>
+int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
+  constexpr bool seam_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU;
+  constexpr bool tall_epi = seam_epi || EPI == EPI_RESID_F32;
+#ifdef VITAMD_EXPERIMENTAL
+  {   // experimental builds: further tile codes select the measured alternatives (experimental/gemm_nt_variants.inc)
+    int tile = p.tile;
+    if (tile >= 24 && tile <= 30) return dispatch_seam_explicit<EPI>(p, stream, tile);
+    if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) {
+      const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
+      if (r != -1) return r;
+      if (tile != 7 && tile != 8) return VITAMD_ERR_ARG;
+      GemmNtArgs q = p;
+      q.tile = tile == 7 ? 256 : 320;
+      return dispatch_tile<EPI>(q, stream);
     }
-    return launch_pp<EPI, 8, 4, 6, true>(p, stream);
+    if (tile == 0 && (VITAMD_DBG(p) & 0x40000000)) return dispatch_variant<EPI>(p, stream, 2, prefer_tall(p));   // dbg bit 30: the round-1 pipe kernel
   }
-  if (tile == 0) tile = (p.N >= 256 && big_tiles >= 192 && pp_ok) ? (tall_epi && prefer_tall(p) ? 320 : 256) : 128;
-  if (tile == 320) {
-    if constexpr (tall_epi) return pp_ok ? launch_pp<EPI, 10, 4, 6>(p, stream) : VITAMD_ERR_SHAPE;
-    return VITAMD_ERR_SHAPE;
+#endif
+  const NtPlan pl = plan_single(p);
+  if (pl.err) return pl.err;
+  switch (pl.form) {
+    case NT_FORM_LOADER:
+      if constexpr (seam_epi) return launch_ld<EPI, EPI == EPI_GELU>(p, stream, device_cus());
+      break;
+    case NT_FORM_SEAM:
+      if constexpr (EPI == EPI_BIAS_BF16) { if (pl.rows == 320) return launch_seam<EPI, 10>(p, stream, device_cus()); }
+      if constexpr (seam_epi) return launch_seam<EPI, 8, 0, EPI == EPI_GELU>(p, stream, device_cus());
+      break;
+    case NT_FORM_PP_PERSISTENT:
+      if constexpr (tall_epi) { if (pl.rows == 320) return launch_pp<EPI, 10, 4, 6, true>(p, stream); }
+      return launch_pp<EPI, 8, 4, 6, true>(p, stream);
+    case NT_FORM_PP:
+      if constexpr (tall_epi) { if (pl.rows == 320) return launch_pp<EPI, 10, 4, 6>(p, stream); }
+      return launch_pp<EPI, 8, 4, 6>(p, stream);
+    case NT_FORM_SMALL:
+      return launch<128, 128, 2, 2, EPI>(p, stream);
   }
-  if (tile == 256) return pp_ok ? launch_pp<EPI, 8, 4, 6>(p, stream) : VITAMD_ERR_SHAPE;
-  if (p.K % BK != 0) return VITAMD_ERR_SHAPE;
-  return launch<128, 128, 2, 2, EPI>(p, stream);
+  return VITAMD_ERR_SHAPE;
 }
 
 }  // namespace
@@ -492,51 +539,85 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
 static int dispatch_epi(const GemmNtArgs& p, hipStream_t stream) {
   switch (p.epi) {
     case EPI_BIAS_BF16: return dispatch_tile<EPI_BIAS_BF16>(p, stream);
-    case EPI_GELU: return p.out2 ? dispatch_tile<EPI_GELU>(p, stream) : VITAMD_ERR_ARG;
-    case EPI_RESID_F32: return p.aux ? dispatch_tile<EPI_RESID_F32>(p, stream) : VITAMD_ERR_ARG;
-    case EPI_DGELU: return p.aux ? dispatch_tile<EPI_DGELU>(p, stream) : VITAMD_ERR_ARG;
-    case EPI_PATCH_F32: return (p.aux && p.n_patches > 0) ? dispatch_tile<EPI_PATCH_F32>(p, stream) : VITAMD_ERR_ARG;
+    case EPI_GELU: return dispatch_tile<EPI_GELU>(p, stream);
+    case EPI_RESID_F32: return dispatch_tile<EPI_RESID_F32>(p, stream);
+    case EPI_DGELU: return dispatch_tile<EPI_DGELU>(p, stream);
+    case EPI_PATCH_F32: return dispatch_tile<EPI_PATCH_F32>(p, stream);
     case EPI_F32: return dispatch_tile<EPI_F32>(p, stream);
     default: return VITAMD_ERR_ARG;
   }
 }
 
-int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
-  if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
-  // One big-tile workgroup per CU means a launch runs in whole rounds of 256 tiles; a last round that is mostly empty idles most of
-  // the chip for a full tile time.  Two remedies live here: the tile height (prefer_tall) and the tail split below.
+// One big-tile workgroup per CU means a launch runs in whole rounds of 256 tiles; a last round that is mostly empty idles most of
+// the chip for a full tile time.  Two remedies: the tile height (prefer_tall) and the tail split decided here.
+// Tail split: the last, mostly empty round of big tiles is re-cut into 128x128 tiles.  Only ever paid for the fused-residual fc2 FORWARD GEMM
+// on 256-row tiles (591 tiles = 2.31 rounds; -0.2 ms/step), which the 320-row tile has since replaced (474 tiles = 1.85 rounds:
+// no split).  Everywhere else it loses on the whole step: +0.9 ms forced on every GEMM (bit 4) because the weight-gradient GEMMs
+// of the side stream already fill the backward tails, +0.2 ms on fc1+GELU at 7.4 rounds of 320-row tiles (the 128x128 kernel's
+// direct-store GELU epilogue costs more than the 0.6 idle round).  Experimental builds: vitamd_set_debug bit 7 turns it off, bit 4 forces it.
+static int tail_split_rows(const GemmNtArgs& p, bool& tall) {       // rows of the head part, 0 = no split
   const int CUS = device_cus();
-  const bool tall = (p.tile == 0 || p.tile == 512 || p.tile == 1024) && prefer_tall(p);
+  tall = (p.tile == 0 || p.tile == 512 || p.tile == 1024) && prefer_tall(p);
   const int bm = tall ? 320 : 256;
   const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + 255) / 256;
   const long big_tiles = (long)tiles_m * tiles_n;
   const long rem = big_tiles % CUS;
-  // Tail split: the last, mostly empty round of big tiles is re-cut into 128x128 tiles.  Only ever paid for the fc2 FORWARD GEMM
-  // on 256-row tiles (591 tiles = 2.31 rounds; -0.2 ms/step), which the 320-row tile has since replaced (474 tiles = 1.85 rounds:
-  // no split).  Everywhere else it loses on the whole step: +0.9 ms forced on every GEMM (bit 4) because the weight-gradient GEMMs
-  // of the side stream already fill the backward tails, +0.2 ms on fc1+GELU at 7.4 rounds of 320-row tiles (the 128x128 kernel's
-  // direct-store GELU epilogue costs more than the 0.6 idle round).  Experimental builds: vitamd_set_debug bit 7 turns it off, bit 4 forces it.
   const bool split_on = (VITAMD_DBG(p) & 16) != 0 || (!(VITAMD_DBG(p) & 128) && p.epi == EPI_RESID_F32 && !tall);
-  if ((p.tile == 0 || p.tile == 512 || p.tile == 1024) && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6) {
-    const int panels_a = (int)((big_tiles - rem) / tiles_n);          // M-panels whose tiles fill whole rounds
-    const int rows_a = panels_a * bm;
-    if (panels_a > 0 && rows_a < p.M) {
-      GemmNtArgs a = p, b = p;
-      a.M = rows_a;
-      a.tile = tall ? p.tile : 256;                                   // (auto picks the 320-row form again for the head part)
-      const size_t esz_out = (p.epi == EPI_RESID_F32 || p.epi == EPI_F32) ? 4 : 2;
-      b.M = p.M - rows_a;
-      b.A = (const char*)p.A + (size_t)rows_a * p.K * 2;
-      b.out = (char*)p.out + (size_t)rows_a * p.ldo * esz_out;
-      if (p.out2) b.out2 = (char*)p.out2 + (size_t)rows_a * p.ldo * 2;
-      if (p.aux) b.aux = (const char*)p.aux + (size_t)rows_a * p.ldo * (p.epi == EPI_RESID_F32 ? 4 : 2);
-      b.tile = 128;
-      b.row0 = p.row0 + rows_a;
-      if (int e = dispatch_epi(a, stream)) return e;
-      return dispatch_epi(b, stream);
-    }
+  if (!((p.tile == 0 || p.tile == 512 || p.tile == 1024) && split_on && p.epi != EPI_PATCH_F32 && p.N >= 256 && p.K % 64 == 0 && big_tiles > 2 * CUS && rem != 0 && rem * 10 < CUS * 6))
+    return 0;
+  const int rows_a = (int)((big_tiles - rem) / tiles_n) * bm;       // M-panels whose tiles fill whole rounds
+  return rows_a > 0 && rows_a < p.M ? rows_a : 0;
+}
+
+static int check_args(const GemmNtArgs& p) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 32 != 0 || p.N % 4 != 0 || p.ldo % 4 != 0) return VITAMD_ERR_SHAPE;
+  if (!p.A || !p.B || !p.out) return VITAMD_ERR_ARG;
+  if (p.epi == EPI_GELU && !p.out2) return VITAMD_ERR_ARG;
+  if ((p.epi == EPI_RESID_F32 || p.epi == EPI_DGELU) && !p.aux) return VITAMD_ERR_ARG;
+  if (p.epi == EPI_PATCH_F32 && (!p.aux || p.n_patches <= 0)) return VITAMD_ERR_ARG;
+  if (p.epi < EPI_BIAS_BF16 || p.epi > EPI_F32) return VITAMD_ERR_ARG;
+  return VITAMD_OK;
+}
+
+int vitamd_gemm_nt_impl(const GemmNtArgs& p0, hipStream_t stream) {
+  if (int e = check_args(p0)) return e;
+  GemmNtArgs p = p0;
+  if (p.epi == EPI_GELU) {                 // ONE rounding of GELU whatever kernel the launch takes: every GELU epilogue reads the table
+    p.gelu_tab = gelu_table();
+    if (!p.gelu_tab) return VITAMD_ERR_INIT;
+  }
+  bool tall = false;
+  const int rows_a = tail_split_rows(p, tall);
+  if (rows_a) {
+    GemmNtArgs a = p, b = p;
+    a.M = rows_a;
+    a.tile = tall ? p.tile : 256;                                   // (auto picks the 320-row form again for the head part)
+    const size_t esz_out = (p.epi == EPI_RESID_F32 || p.epi == EPI_F32) ? 4 : 2;
+    b.M = p.M - rows_a;
+    b.A = (const char*)p.A + (size_t)rows_a * p.K * 2;
+    b.out = (char*)p.out + (size_t)rows_a * p.ldo * esz_out;
+    if (p.out2) b.out2 = (char*)p.out2 + (size_t)rows_a * p.ldo * 2;
+    if (p.aux) b.aux = (const char*)p.aux + (size_t)rows_a * p.ldo * (p.epi == EPI_RESID_F32 ? 4 : 2);
+    b.tile = 128;
+    b.row0 = p.row0 + rows_a;
+    if (int e = dispatch_epi(a, stream)) return e;
+    return dispatch_epi(b, stream);
   }
   return dispatch_epi(p, stream);
 }
 
+// vitamd_gemm_nt_plan: the kernel form vitamd_gemm_nt_bf16 would launch for these arguments on the current device, without launching:
+// form | rows << 8 (| 0x80: the launch is cut into a head of whole rounds in that form and a tail on 128x128 tiles), or -VITAMD_ERR_*.
+int vitamd_gemm_nt_plan_impl(const GemmNtArgs& p0) {
+  if (int e = check_args(p0)) return -e;
+  bool tall = false;
+  GemmNtArgs p = p0;
+  const int rows_a = tail_split_rows(p, tall);
+  if (rows_a) {
+    p.M = rows_a;
+    p.tile = tall ? p.tile : 256;
+  }
+  const NtPlan pl = plan_single(p);
+  if (pl.err) return -pl.err;
+  return pl.form | (pl.rows << 8) | (rows_a ? 0x80 : 0);
+}

@@ -7,6 +7,49 @@ namespace {
 
 constexpr int BK = 64;  // bf16 elements per K-tile = 128 B per LDS row
 
+// erf-GELU by table for bf16 inputs (every EPI_GELU epilogue).  The pre-activation reaches the epilogue rounded to bf16 (autocast's Linear output,
+// transformer.py:37-38), so gelu(x) and gelu'(x) are functions of 16 bits: for 2^-13 <= |x| < 8 (16 exponents x 128 mantissas x 2 signs = 4096
+// inputs) the table holds bf16(gelu(x)) | bf16(gelu'(x)) << 16, correctly rounded from double (gemm_nt.hip::vitamd_init_impl builds the device
+// image).  `tab` is the LDS copy in the persistent kernels (seam / loader forms: two ds_read_b32 per pair) and the device image itself in the
+// others (small problems: 4-byte gathers that hit the 16-KiB image in L1) - ONE rounding of GELU whatever kernel a launch takes.
+// Per PAIR of elements: 9 packed-16-bit / 32-bit integer operations, two table reads and two v_perm against ~41 VALU-equivalents of the
+// erf / exp / rcp formula (two quarter-rate transcendentals per element).  Inputs outside the table (|x| < 2^-13, |x| >= 8, inf, nan: ~1e-4 of
+// N(0,1) data) take the formula - a wave-uniform branch, per element.  V = u32x4 (8 elements) or u32x2 (4).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <typename V>
+__device__ __forceinline__ void gelu_lookup(const V& v, const char* tab, bool want_dg, V& a, V& d) {
+  constexpr int NPR = (int)(sizeof(V) / 4);
+  constexpr unsigned T_LO = 0x3900u;                 // bf16 bits of 2^-13; the table ends below 0x4100 = 8.0
+  unsigned r[NPR], any = 0u;
+#pragma unroll
+  for (int c = 0; c < NPR; ++c) {
+    const unsigned t = v[c] & 0x7fff7fffu;
+    const u16x2 rr = __builtin_bit_cast(u16x2, t) - (u16x2){(unsigned short)T_LO, (unsigned short)T_LO};      // wraps below the table
+    r[c] = __builtin_bit_cast(unsigned, rr);
+    any |= r[c];
+    const u16x2 rc = __builtin_elementwise_min(rr, (u16x2){2047, 2047});
+    // byte offset of entry sign x 2048 + index in each half: plain 32-bit arithmetic (no carry between the halves: index <= 4095).  Written this
+    // way on purpose: with the sign taken by a packed 16-bit shift inside this unrolled loop hipcc 7.2 used pair 0's sign for all four pairs.
+    const unsigned b = (__builtin_bit_cast(unsigned, rc) | ((v[c] >> 4) & 0x08000800u)) << 2;
+    const unsigned elo = *(const unsigned*)(tab + (b & 0xffffu));
+    const unsigned ehi = *(const unsigned*)(tab + (b >> 16));
+    a[c] = __builtin_amdgcn_perm(ehi, elo, 0x05040100u);
+    if (want_dg) d[c] = __builtin_amdgcn_perm(ehi, elo, 0x07060302u);
+  }
+  if (__builtin_amdgcn_ballot_w64((any & 0xf800f800u) != 0u)) {                    // an index >= 2048 in some lane of the wave
+#pragma unroll
+    for (int c = 0; c < NPR; ++c) {
+      float dlo, dhi;
+      const unsigned g = pack_bf16x2(gelu_fwd_grad(bf16lo(v[c]), dlo), gelu_fwd_grad(bf16hi(v[c]), dhi));
+      const unsigned dg = pack_bf16x2(dlo, dhi);
+      const unsigned m = ((r[c] & 0xf800u) ? 0xffffu : 0u) | ((r[c] & 0xf8000000u) ? 0xffff0000u : 0u);
+      a[c] = (g & m) | (a[c] & ~m);
+      if (want_dg) d[c] = (dg & m) | (d[c] & ~m);
+    }
+  }
+}
+__device__ __forceinline__ void gelu_lookup8(const u32x4& v, const char* tab, bool want_dg, u32x4& a, u32x4& d) { gelu_lookup<u32x4>(v, tab, want_dg, a, d); }
+
 // Shared epilogue: acc[i][j][r] = C[m][n] with m = m0 + wm*WTM + i*16 + (lane&15),
 // n = n0 + wn*WTN + j*16 + 4*(lane>>4) + r  (A/B swapped MFMA: each lane owns 4 consecutive columns).
 template <int BN, int WM, int WN, int WTM, int WTN, int MT, int NT, int EPI>
@@ -47,16 +90,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
         u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         *(u32x2*)((__bf16*)p.out + (size_t)m * ldo + n) = o;
       } else if constexpr (EPI == EPI_GELU) {
-        f32x4 pre, act;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pre[r] = round_bf16(v[r]);
-          float dg;
-          act[r] = (VITAMD_DBG(p) & 1) ? pre[r] : gelu_fwd_grad(pre[r], dg);
-          if (p.gelu_dg) pre[r] = dg;                       // `out` carries gelu'(pre) for the backward
-        }
-        u32x2 o1 = {pack_bf16x2(pre[0], pre[1]), pack_bf16x2(pre[2], pre[3])};
-        u32x2 o2 = {pack_bf16x2(act[0], act[1]), pack_bf16x2(act[2], act[3])};
+        const u32x2 pz = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};       // the Linear output, rounded to bf16
+        u32x2 o1 = pz, o2;                                                           // `out` carries the pre-activation, or gelu'(pre) for the backward (gelu_dg)
+        gelu_lookup<u32x2>(pz, (const char*)p.gelu_tab, p.gelu_dg != 0, o2, o1);
         *(u32x2*)((__bf16*)p.out + (size_t)m * ldo + n) = o1;
         if (!(VITAMD_DBG(p) & 2)) *(u32x2*)((__bf16*)p.out2 + (size_t)m * ldo + n) = o2;
       } else if constexpr (EPI == EPI_RESID_F32) {
@@ -224,13 +260,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmNtArgs& p, f32x4 (&
       if (ok) ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), v);
     } else if constexpr (EPI == EPI_GELU) {
       u32x4 a;
-      u32x4 d = v;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float dlo, dhi;
-        a[c] = pack_bf16x2(gelu_fwd_grad(bf16lo(v[c]), dlo), gelu_fwd_grad(bf16hi(v[c]), dhi));
-        if (p.gelu_dg) d[c] = pack_bf16x2(dlo, dhi);       // `out` carries gelu'(pre) for the backward
-      }
+      u32x4 d = v;                                          // `out` carries the pre-activation, or gelu'(pre) for the backward (gelu_dg)
+      gelu_lookup8(v, (const char*)p.gelu_tab, p.gelu_dg != 0, a, d);
       if (ok) {
         ST16((u32x4*)((__bf16*)p.out + (size_t)m * ldo + n), d);
         ST16((u32x4*)((__bf16*)p.out2 + (size_t)m * ldo + n), a);

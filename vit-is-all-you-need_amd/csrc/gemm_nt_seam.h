@@ -72,44 +72,6 @@ struct SeamSchedule {
   }
 };
 
-// erf-GELU by table for bf16 inputs (EPI_GELU on the 256-row seam kernel).  The pre-activation reaches this point rounded to bf16 (autocast's
-// Linear output, transformer.py:37-38), so gelu(x) and gelu'(x) are functions of 16 bits: for 2^-13 <= |x| < 8 (16 exponents x 128 mantissas x 2
-// signs = 4096 inputs) the LDS image holds bf16(gelu(x)) | bf16(gelu'(x)) << 16, correctly rounded from double (gelu_table() in gemm_nt.hip).
-// Per PAIR of elements: 9 packed-16-bit / 32-bit integer operations, two ds_read_b32 and two v_perm against ~41 VALU-equivalents of the
-// erf / exp / rcp formula (two quarter-rate transcendentals per element).  Inputs outside the table (|x| < 2^-13, |x| >= 8, inf, nan: ~1e-4 of
-// N(0,1) data) take the formula - a wave-uniform branch, per element.
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu_lookup8(const u32x4& v, const char* tab, bool want_dg, u32x4& a, u32x4& d) {
-  constexpr unsigned T_LO = 0x3900u;                 // bf16 bits of 2^-13; the table ends below 0x4100 = 8.0
-  unsigned r[4], any = 0u;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const unsigned t = v[c] & 0x7fff7fffu;
-    const u16x2 rr = __builtin_bit_cast(u16x2, t) - (u16x2){(unsigned short)T_LO, (unsigned short)T_LO};      // wraps below the table
-    r[c] = __builtin_bit_cast(unsigned, rr);
-    any |= r[c];
-    const u16x2 rc = __builtin_elementwise_min(rr, (u16x2){2047, 2047});
-    // byte offset of entry sign x 2048 + index in each half: plain 32-bit arithmetic (no carry between the halves: index <= 4095).  Written this
-    // way on purpose: with the sign taken by a packed 16-bit shift inside this unrolled loop hipcc 7.2 used pair 0's sign for all four pairs.
-    const unsigned b = (__builtin_bit_cast(unsigned, rc) | ((v[c] >> 4) & 0x08000800u)) << 2;
-    const unsigned elo = *(const unsigned*)(tab + (b & 0xffffu));
-    const unsigned ehi = *(const unsigned*)(tab + (b >> 16));
-    a[c] = __builtin_amdgcn_perm(ehi, elo, 0x05040100u);
-    if (want_dg) d[c] = __builtin_amdgcn_perm(ehi, elo, 0x07060302u);
-  }
-  if (__builtin_amdgcn_ballot_w64((any & 0xf800f800u) != 0u)) {                    // an index >= 2048 in some lane of the wave
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float dlo, dhi;
-      const unsigned g = pack_bf16x2(gelu_fwd_grad(bf16lo(v[c]), dlo), gelu_fwd_grad(bf16hi(v[c]), dhi));
-      const unsigned dg = pack_bf16x2(dlo, dhi);
-      const unsigned m = ((r[c] & 0xf800u) ? 0xffffu : 0u) | ((r[c] & 0xf8000000u) ? 0xffff0000u : 0u);
-      a[c] = (g & m) | (a[c] & ~m);
-      if (want_dg) d[c] = (dg & m) | (d[c] & ~m);
-    }
-  }
-}
-
 template <int EPI, int MT, int RQ = 0, bool TAB = false>
 __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
   static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU, "epilogues without (or with up-front) auxiliary loads");

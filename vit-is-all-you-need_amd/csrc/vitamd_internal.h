@@ -32,7 +32,7 @@ struct GemmNtArgs {
   // stored-derivative GELU (ABI codes VITAMD_EPI_GELU_DG / VITAMD_EPI_DMUL): EPI_GELU writes out = bf16(gelu'(pre)) instead
   // of pre, EPI_DGELU multiplies by aux as stored instead of evaluating gelu'(aux)
   int gelu_dg;
-  const unsigned* gelu_tab;   // device image of gelu_table() (set by the dispatcher for the table form of the seam kernel, else null)
+  const unsigned* gelu_tab;   // EPI_GELU: device image of the erf-GELU table (vitamd_init; set by vitamd_gemm_nt_impl for every GELU launch)
 };
 
 struct GemmTnArgs {
@@ -48,6 +48,8 @@ struct GemmTnArgs {
 };
 
 int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream);
+int vitamd_gemm_nt_plan_impl(const GemmNtArgs& p);
+int vitamd_init_impl(int device, hipStream_t stream);
 int vitamd_gemm_tn_impl(const GemmTnArgs& p, hipStream_t stream);
 // experimental builds only: 256x384-tile weight-gradient kernel (experimental/gemm_tn_wide.hip)
 bool vitamd_gemm_tn_wide_ok(int R, int P, int Q, int requested_splits);

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitamd.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c = ctypes
 _P, _I, _F, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_ulonglong
@@ -20,6 +20,8 @@ _P, _I, _F, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_ulongl
 # name -> argtypes ; every function returns int (VITAMD_OK == 0)
 SIGNATURES = {
     "vitamd_abi_version": [],
+    "vitamd_init": [_I, _P],
+    "vitamd_gemm_nt_plan": [_I, _I, _I, _I, _I, _I],
     "vitamd_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vitamd_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vitamd_gemm_tn_bf16_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P],
@@ -51,7 +53,7 @@ SIGNATURES = {
     "vitamd_adamw_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
 }
 
-ERRORS = {1: "unsupported shape", 2: "bad argument", 3: "HIP launch failure"}
+ERRORS = {1: "unsupported shape", 2: "bad argument", 3: "HIP launch failure", 4: "vitamd_init has not run for this device"}
 
 _lib = None
 

@@ -33,6 +33,23 @@ def _L():
     return _lib.load()
 
 
+_INITIALISED = set()     # device indices vitamd_init has run for
+
+
+def init(device=None):
+    """Per-device set-up of the library (C ABI vitamd_init: builds the 16-KiB erf-GELU table image - the only allocation / synchronisation the
+    library ever makes).  Idempotent and cheap after the first call; called by the GEMM wrapper before a GELU launch, by functions.claim_streams
+    and by GraphedStep's eager warm-up, so it never first happens inside a stream capture."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _INITIALISED:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.VitamdError("vitamd.ops.init: first use of a device inside a stream capture; run one eager step (or ops.init(device)) before capturing")
+    _lib.check(_L().vitamd_init(idx, torch.cuda.current_stream(device).cuda_stream), f"vitamd_init[device {idx}]")
+    _INITIALISED.add(idx)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -70,6 +87,8 @@ def gemm_nt(a, b, epi, *, bias=None, aux=None, out=None, out2=None, colsum=None,
         out2 = torch.empty((M, N), dtype=BF16, device=a.device)
     if bias is not None:
         _need(bias, F32, "bias", 1)
+    if epi in (EPI_GELU, EPI_GELU_DG):
+        init(a.device)
     if tile == 0 and not NT_PERSISTENT:
         tile = 512                      # automatic tile choice, one workgroup per tile
     elif tile == 0 and K <= 1536 and M * N >= (1 << 26):     # the shapes the seam rule can apply to (cheap pre-filter; the library decides)
