@@ -18,6 +18,8 @@ int g_vitamd_debug = 0;
 //   TN GEMM : 6 round-1 16x16x32 form   25 256x384-tile kernel   26-28: 1-3 round-1 timing ablations(!), 5 round-1 LDS-DMA, 6 round-1 VGPR-staged, 7 ping-pong D = 6
 //   attention: 9 one-pass fused backward   10-12 its timing probes(!)
 extern "C" int vitamd_set_debug(int bits) { g_vitamd_debug = bits; return 0; }
+int g_vitamd_debug2 = 0;     // second word (experiments of round 4 on: the first one is full): bits 0-3 = which launch classes take the loader-wave NT form (gemm_nt.hip::ld_auto)
+extern "C" int vitamd_set_debug2(int bits) { g_vitamd_debug2 = bits; return 0; }
 #endif
 
 extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void* out2, const float* bias, const void* aux,
@@ -29,7 +31,7 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
   if (epi == 7) epi = EPI_DGELU;
   GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, VITAMD_GDBG, 0u, 1.0f, 0u, 0u, 0, dg};
 #ifdef VITAMD_EXPERIMENTAL
-  if (!(tile >= 0 && tile <= 30) && tile != 128 && tile != 256 && tile != 257 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) return VITAMD_ERR_ARG;
+  if (!(tile >= 0 && tile <= 30) && tile != 128 && tile != 256 && tile != 257 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048 && tile != 2049) return VITAMD_ERR_ARG;
 #else
   if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) return VITAMD_ERR_ARG;
 #endif

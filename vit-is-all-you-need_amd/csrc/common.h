@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // library every knob reads as the constant 0 and the code behind it is compiled out.
 #ifdef VITAMD_EXPERIMENTAL
 extern int g_vitamd_debug;
+extern int g_vitamd_debug2;
 #define VITAMD_DBG(p) ((p).dbg)
 #define VITAMD_GDBG g_vitamd_debug
 #else

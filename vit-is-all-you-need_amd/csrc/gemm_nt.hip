@@ -449,6 +449,16 @@ struct NtPlan { int form, rows, err; };
 
 // The loader-wave form (gemm_nt_ld.h) in the automatic choice: see LD_AUTO in DESIGN.md section 4.7 for the measurements behind the rule.
 static bool ld_auto(const GemmNtArgs& p, long big_tiles, int cus) {
+#ifdef VITAMD_EXPERIMENTAL
+  // whole-step A/B (tools/ab_ld.py; a debug word of its own, vitamd_set_debug2): bit 0 = plain-bias launches with a short K loop (QKV), 1 = GELU,
+  // 2 = dGELU-multiply, 3 = plain-bias launches with a long K loop (the N = 768 GEMMs: three rounds of 256-row tiles where gemm_nt_pp_kernel runs
+  // two of 320 rows)
+  const int d = g_vitamd_debug2;
+  if (p.epi == EPI_BIAS_BF16 && p.K <= 1536 && big_tiles >= 3L * cus) return (d & 1) != 0;
+  if (p.epi == EPI_GELU && p.K <= 1536 && big_tiles >= 3L * cus) return (d & 2) != 0;
+  if (p.epi == EPI_DGELU && p.K <= 1536 && big_tiles >= 3L * cus) return (d & 4) != 0;
+  if (p.epi == EPI_BIAS_BF16 && p.K > 1536) return (d & 8) != 0;
+#endif
   (void)p; (void)big_tiles; (void)cus;
   return false;
 }
@@ -501,6 +511,10 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   {   // experimental builds: further tile codes select the measured alternatives (experimental/gemm_nt_variants.inc)
     int tile = p.tile;
     if (tile >= 24 && tile <= 30) return dispatch_seam_explicit<EPI>(p, stream, tile);
+    if (tile == 2049) {                     // the loader-wave form with its first request schedule (burst in phase 0)
+      if constexpr (seam_epi) return ld_ok(p) ? launch_ld<EPI, EPI == EPI_GELU, 0>(p, stream, device_cus()) : VITAMD_ERR_SHAPE;
+      return VITAMD_ERR_SHAPE;
+    }
     if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) {
       const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
       if (r != -1) return r;

@@ -30,7 +30,10 @@
 
 namespace {
 
-template <int EPI, bool TAB = false>
+// SCHED: how the loaders spread a K-tile's 16 requests (each) over its four phases.  0 = as early as the ring allows (12 in phase 0, 4 in phase 1:
+// 3.5 phases in flight, but the burst - ~60 cycles per piece - makes the loaders late for phase 0's barrier); 1 = 6 / 6 / 4 / 0, half of each
+// phase's requests behind its first barrier (2.5 phases in flight, <= 360 cycles of issue per phase): the shipped form.
+template <int EPI, bool TAB = false, int SCHED = 1>
 __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const GemmNtArgs p) {
   static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU, "epilogues of the loader form");
   static_assert(!TAB || EPI == EPI_GELU, "table = GELU");
@@ -73,35 +76,50 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const GemmNtArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int a = 4 * l + i;
-          const int row = min(t.m0 + (a >> 3) * 128 + h * 64 + (a & 7) * 8 + r8, p.M - 1);      // clamp: rows past M are never stored
+          const int row = min(((VITAMD_DBG(p) & 4) ? (t.m0 & 0x3ff) : t.m0) + (a >> 3) * 128 + h * 64 + (a & 7) * 8 + r8, p.M - 1);      // clamp: rows past M are never stored (dbg bit 2, timing only: every tile loads one of four L2-resident A panels)
           voffA[h][i] = (unsigned)row * (unsigned)(K * 2) + chunk;
+          if (VITAMD_DBG(p) & 16) voffA[h][i] = (unsigned)min(t.m0, p.M - 256) * (unsigned)(K * 2) + (unsigned)((h * 16 + a) * 1024 + lane * 16);   // (dbg bit 4, timing only: every piece = 1 KiB CONTIGUOUS of the same panel - what a K-tile-blocked operand layout would fetch)
         }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int row = min(t.n0 + (8 * l + i) * 8 + r8, p.N - 1);
+        const int row = min(((VITAMD_DBG(p) & 8) ? 0 : t.n0) + (8 * l + i) * 8 + r8, p.N - 1);      // (dbg bit 3, timing only: every tile loads the first B panel)
         voffB[i] = (unsigned)row * (unsigned)(K * 2) + chunk;
+        if (VITAMD_DBG(p) & 32) voffB[i] = (unsigned)min(t.n0, p.N - 256) * (unsigned)(K * 2) + (unsigned)((8 * l + i) * 1024 + lane * 16);     // (dbg bit 5: the same for B)
       }
     };
     // K-tile kt of the tile whose offsets are loaded; !live: past the last tile - requested out of range (zero fill, no traffic) so that the
-    // counts are the same in every iteration
-    auto request_b_a0 = [&](int kt, bool live) {
-      const unsigned so = live ? (unsigned)kt * 128u : 0u, par = (unsigned)(kt & 1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) asm_glds16(srdB, ldsB + par * BBUF + i * 1024, live ? voffB[i] : OOB, so);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm_glds16(srdA, ldsA + par * ABUF + i * 1024, live ? voffA[0][i] : OOB, so);
+    // counts are the same in every iteration.  (experimental builds, timing only, results garbage: dbg bit 0 = every request out of range - the
+    // instruction is issued, nothing is fetched; dbg bit 1 = no request instructions at all)
+    bool live = true;
+    unsigned so = 0u, soA = 0u, soB = 0u, par = 0u;
+    auto request_b = [&](int i) {
+      if (VITAMD_DBG(p) & 2) return;
+      asm_glds16(srdB, ldsB + par * BBUF + i * 1024, live ? voffB[i] : OOB, soB);
     };
-    auto request_a1 = [&](int kt, bool live) {
-      const unsigned so = live ? (unsigned)kt * 128u : 0u, par = (unsigned)(kt & 1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm_glds16(srdA, ldsA + par * ABUF + AREG + i * 1024, live ? voffA[1][i] : OOB, so);
+    auto request_a = [&](int h, int i) {
+      if (VITAMD_DBG(p) & 2) return;
+      asm_glds16(srdA, ldsA + par * ABUF + h * AREG + i * 1024, live ? voffA[h][i] : OOB, soA);
     };
+    auto target = [&](int kt, bool lv) {                // the K-tile the following requests fetch
+      live = lv && !(VITAMD_DBG(p) & 1);
+      so = live ? (unsigned)kt * 128u : 0u;
+      soA = (VITAMD_DBG(p) & 16) ? so * 256u : so;      // contiguous-piece ablations: a K-tile of a 256-row panel = 32 KiB
+      soB = (VITAMD_DBG(p) & 32) ? so * 256u : so;
+      par = (unsigned)(kt & 1);
+    };
+    __builtin_amdgcn_s_setprio(3);                      // the loaders' few instructions go first: a late request costs every wave of the workgroup
     int ti = blockIdx.x;
     Tile cur = coords(ti);
     offsets(cur);
     int bias_n0 = cur.n0;
-    request_b_a0(0, true);
-    request_a1(0, true);
+    target(0, true);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) request_b(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) request_a(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) request_a(1, i);
+    if (VITAMD_DBG(p) & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
     VITAMD_WAIT_VM(4);                                  // B(0), A0(0) landed; A1(0) is waited for in iteration (0, 0)
     __builtin_amdgcn_s_barrier();                       // START
     for (;;) {
@@ -113,30 +131,62 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const GemmNtArgs p) {
           cur = coords(ti_next);
           offsets(cur);
         }
-        const bool live = !last || has_next;
-        const int nk = last ? 0 : kt + 1;
-        // ---- phase 0: the buffer of K-tile kt - 1 is free in its B and A0 parts (last read two phases ago)
-        request_b_a0(nk, live);
-        __builtin_amdgcn_s_barrier();
-        VITAMD_WAIT_VM(12);                             // A1(kt) (first read in phase 1) has landed
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 1
-        if constexpr (EPI != EPI_DGELU) {
-          // first K-tile of a tile: every compute wave is inside the main loop, its staging image idle - the bias of ITS 64 columns goes there
-          // (256 B by LDS-DMA; both wave rows), long before the epilogue reads it
-          if (kt == 0) {
-            asm_glds4(srdBias, lds_addr(smem) + OPS + l * STG, (unsigned)(bias_n0 + l * 64 + lane) * 4u, 0u);
-            asm_glds4(srdBias, lds_addr(smem) + OPS + (4 + l) * STG, (unsigned)(bias_n0 + l * 64 + lane) * 4u, 0u);
+        target(last ? 0 : kt + 1, !last || has_next);
+        // The buffer these requests fill held K-tile kt - 1: its B and A0 parts were last read in phase 2 of that K-tile (free from phase 0
+        // of this one), its A1 part in phase 3 (free behind the first barrier of phase 0).  First reads: B, A0 in phase 0 of the next
+        // K-tile (waited for in phase 3), A1 in its phase 1 (waited for in its phase 0).
+        if constexpr (SCHED == 0) {
+          // ---- phase 0
+#pragma unroll
+          for (int i = 0; i < 8; ++i) request_b(i);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) request_a(0, i);
+          __builtin_amdgcn_s_barrier();
+          VITAMD_WAIT_VM(12);                           // A1(kt) (first read in phase 1) has landed
+          __builtin_amdgcn_s_barrier();
+          // ---- phase 1
+          if constexpr (EPI != EPI_DGELU) {
+            if (kt == 0) {
+              asm_glds4(srdBias, lds_addr(smem) + OPS + l * STG, (unsigned)(bias_n0 + l * 64 + lane) * 4u, 0u);
+              asm_glds4(srdBias, lds_addr(smem) + OPS + (4 + l) * STG, (unsigned)(bias_n0 + l * 64 + lane) * 4u, 0u);
+            }
           }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) request_a(1, i);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_s_barrier();
+          // ---- phase 2
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_s_barrier();
+        } else {
+          // ---- phase 0: B pieces 0-5
+          request_b(0); request_b(1); request_b(2);
+          __builtin_amdgcn_s_barrier();
+          request_b(3); request_b(4); request_b(5);
+          VITAMD_WAIT_VM(6);                            // A1(kt) (first read in phase 1) has landed
+          __builtin_amdgcn_s_barrier();
+          // ---- phase 1: B pieces 6, 7 and A0
+          if constexpr (EPI != EPI_DGELU) {
+            // first K-tile of a tile: every compute wave is inside the main loop, its staging image idle - the bias of ITS 64 columns goes there
+            // (256 B by LDS-DMA; both wave rows), long before the epilogue reads it
+            if (kt == 0) {
+              asm_glds4(srdBias, lds_addr(smem) + OPS + l * STG, (unsigned)(bias_n0 + l * 64 + lane) * 4u, 0u);
+              asm_glds4(srdBias, lds_addr(smem) + OPS + (4 + l) * STG, (unsigned)(bias_n0 + l * 64 + lane) * 4u, 0u);
+            }
+          }
+          request_b(6); request_b(7); request_a(0, 0);
+          __builtin_amdgcn_s_barrier();
+          request_a(0, 1); request_a(0, 2); request_a(0, 3);
+          __builtin_amdgcn_s_barrier();
+          // ---- phase 2: A1
+          request_a(1, 0); request_a(1, 1);
+          __builtin_amdgcn_s_barrier();
+          request_a(1, 2); request_a(1, 3);
+          __builtin_amdgcn_s_barrier();
         }
-        request_a1(nk, live);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 2
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
         // ---- phase 3
         __builtin_amdgcn_s_barrier();
+        if (VITAMD_DBG(p) & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
         VITAMD_WAIT_VM(4);                              // B, A0 of the next K-tile (first read in its phase 0) have landed; its A1 may be in flight
         __builtin_amdgcn_s_barrier();
       }
@@ -311,9 +361,9 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const GemmNtArgs p) {
 #undef VITAMD_WAIT_VM
 }
 
-template <int EPI, bool TAB = false>
+template <int EPI, bool TAB = false, int SCHED = 1>
 int launch_ld(const GemmNtArgs& p, hipStream_t stream, int cus) {
-  auto kern = gemm_nt_ld_kernel<EPI, TAB>;
+  auto kern = gemm_nt_ld_kernel<EPI, TAB, SCHED>;
   if (TAB && !p.gelu_tab) return VITAMD_ERR_ARG;
   if (int e = set_lds(kern, 160 * 1024)) return e;
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
