@@ -27,9 +27,9 @@ calls = [
     ("dgrad_qkv", lambda t: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 3 * D),
 ]
 cfgs = {"auto": (0, 0), "loader": (2048, 0)}
-if EXP: cfgs.update({"ld_burst": (2049, 0), "ld_oob": (2048, 1), "ld_noreq": (2048, 2), "ld_Ares": (2048, 4), "ld_Bres": (2048, 8), "ld_ABres": (2048, 12), "ld_Acont": (2048, 16), "ld_Bcont": (2048, 32), "ld_ABcont": (2048, 48)})
+if EXP: cfgs.update({"ld_burst": (2049, 0), "ld_oob": (2048, 1), "ld_noreq": (2048, 2), "ld_Ares": (2048, 4), "ld_Bres": (2048, 8), "ld_ABres": (2048, 12), "ld_Acont": (2048, 16), "ld_ABcont": (2048, 48)})
 def setdbg(d):
-    if EXP: _lib.load().vitamd_set_debug(d)
+    if EXP: _lib.load().vitamd_set_debug(d & 0xff); _lib.load().vitamd_set_debug2(d >> 8 << 8)
 tot = {k: 0.0 for k in cfgs}
 for name, fn, fl in calls:
     ref = None

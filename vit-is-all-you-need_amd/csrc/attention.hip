@@ -983,6 +983,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pipe_kernel(const AttnArg
 
 #ifdef VITAMD_EXPERIMENTAL
 #include "experimental/attention_fused.inc"
+#include "experimental/attention_split.inc"
 #endif
 
 // ------------------------------------------------------------------------------------------ long sequences (N > 512)
@@ -1411,6 +1412,16 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
   const int nkt = npad / 32;
   if (!a.drop_thresh && !a.causal && nkt >= 2 && nkt <= 8 && !(VITAMD_GDBG & 0x20000)) {     // the ViT shapes: pipelined forms (dbg bit 17 of experimental builds: the plain loops)
     int e = VITAMD_OK;
+#ifdef VITAMD_EXPERIMENTAL
+    if (nkt <= 7 && (g_vitamd_debug2 & 16)) {            // one staging of the head, split roles (attn_bwd_split_kernel)
+      const int lds3 = 4 * npad * 128 + 2 * npad * 4 + 8 * 4096;
+#define SPLIT(K) case K: e = set_lds(attn_bwd_split_kernel<K>, lds3); if (!e) hipLaunchKernelGGL(attn_bwd_split_kernel<K>, grid, dim3(512), lds3, stream, a); break;
+      switch (nkt) { SPLIT(2) SPLIT(3) SPLIT(4) SPLIT(5) SPLIT(6) SPLIT(7) }
+#undef SPLIT
+      if (e) return e;
+      return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+    }
+#endif
 #define DQ_PIPE(K) case K: e = set_lds(attn_bwd_dq_pipe_kernel<K>, lds1); if (!e) hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel<K>, grid, block, lds1, stream, a); break;
     switch (nkt) { DQ_PIPE(2) DQ_PIPE(3) DQ_PIPE(4) DQ_PIPE(5) DQ_PIPE(6) DQ_PIPE(7) DQ_PIPE(8) }
 #undef DQ_PIPE

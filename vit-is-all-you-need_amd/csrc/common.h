@@ -87,6 +87,23 @@ __device__ __forceinline__ void asm_glds16(srd_t srd, unsigned lds_dst, unsigned
                : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
+// the same with a cache policy on the load (POL 1 = nt, 2 = sc1, 3 = sc0 sc1: all served from L2 without keeping the line in this CU's L1)
+template <int POL>
+__device__ __forceinline__ void asm_glds16_pol(srd_t srd, unsigned lds_dst, unsigned voff, unsigned soff) {
+  unsigned keep;
+  if constexpr (POL == 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+  else if constexpr (POL == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen sc1 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+  else if constexpr (POL == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen sc0 sc1 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+  else
+    asm_glds16(srd, lds_dst, voff, soff);
+}
+
 // 4 B per lane from srd[voff + soff] to LDS byte address lds_dst (wave-uniform) + 4*lane: one row of 64 floats per wave-instruction
 __device__ __forceinline__ void asm_glds4(srd_t srd, unsigned lds_dst, unsigned voff, unsigned soff) {
   unsigned keep;

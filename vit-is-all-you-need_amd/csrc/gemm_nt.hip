@@ -596,6 +596,9 @@ static int check_args(const GemmNtArgs& p) {
 int vitamd_gemm_nt_impl(const GemmNtArgs& p0, hipStream_t stream) {
   if (int e = check_args(p0)) return e;
   GemmNtArgs p = p0;
+#ifdef VITAMD_EXPERIMENTAL
+  p.dbg2 = g_vitamd_debug2;
+#endif
   if (p.epi == EPI_GELU) {                 // ONE rounding of GELU whatever kernel the launch takes: every GELU epilogue reads the table
     p.gelu_tab = gelu_table();
     if (!p.gelu_tab) return VITAMD_ERR_INIT;

@@ -92,6 +92,9 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const GemmNtArgs p) {
     // instruction is issued, nothing is fetched; dbg bit 1 = no request instructions at all)
     bool live = true;
     unsigned so = 0u, soA = 0u, soB = 0u, par = 0u;
+    // (cache policies on these requests - nt, sc1, sc0 sc1 - were measured in round 4: sc1 equal, nt and sc0 sc1 3-8 % slower, and the two extra scalar
+    // branches per request that selecting them at run time cost made the whole kernel 20-40 % slower: the loaders' issue loop is on every barrier's
+    // critical path; profiles/r04/nt_loader_cache_policy.log)
     auto request_b = [&](int i) {
       if (VITAMD_DBG(p) & 2) return;
       asm_glds16(srdB, ldsB + par * BBUF + i * 1024, live ? voffB[i] : OOB, soB);

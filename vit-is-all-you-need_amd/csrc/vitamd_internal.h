@@ -32,6 +32,7 @@ struct GemmNtArgs {
   // stored-derivative GELU (ABI codes VITAMD_EPI_GELU_DG / VITAMD_EPI_DMUL): EPI_GELU writes out = bf16(gelu'(pre)) instead
   // of pre, EPI_DGELU multiplies by aux as stored instead of evaluating gelu'(aux)
   int gelu_dg;
+  int dbg2;                   // second word of A/B bits (experimental builds; vitamd_set_debug2)
   const unsigned* gelu_tab;   // EPI_GELU: device image of the erf-GELU table (vitamd_init; set by vitamd_gemm_nt_impl for every GELU launch)
 };
 
