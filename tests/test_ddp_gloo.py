@@ -204,6 +204,47 @@ def test_choose_launch_form_with_stub_timer_sets_runtime_switches():
         functions.TN_TARGET_WGS = None
 
 
+def _form_worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "vit-is-all-you-need_amd"))
+    from vitamd import ddp, ops
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keep = ops.NT_PERSISTENT
+
+    def measure(form):                       # rank 1 cannot measure the first form (an out-of-memory, say); rank 0 would pick per_tile
+        if rank == 1 and form:
+            raise RuntimeError("HIP out of memory (stub)")
+        return 35.3 if form else 33.0
+
+    rec = ddp.choose_launch_form("cpu", measure=measure)
+    t = torch.tensor([float(rank + 1)])      # the NEXT collective of the job: both ranks must still be in step
+    dist.all_reduce(t)
+    q.put((rank, rec["source"], rec["chosen"], ops.NT_PERSISTENT == keep, float(t.item()), len(rec.get("errors", []))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_choose_launch_form_survives_a_failing_rank_world2():
+    """a measurement that fails on ONE rank must not leave the others blocked in the MAX all-reduces or with a different launch form:
+    the failing rank feeds +inf into the same collectives, every rank keeps the default, and the job's next collective still matches."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_form_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r[1:]) for r in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        source, chosen, kept, total, nerr = results[r]
+        assert source.startswith("default") and kept and total == 3.0, results
+    assert results[0][1] == results[1][1] and results[1][4] == 1 and results[0][4] == 0
+
+
 def test_hw_queue_guard():
     import sys
     import pytest
@@ -211,6 +252,7 @@ def test_hw_queue_guard():
     from vitamd import ddp
     shared, apart = [("box", 0), ("box", 0)], [("box", 0), ("box", 1)]
     ddp.check_hw_queues(shared, environ={})                          # default queue count: fine
+    ddp.check_hw_queues(shared, environ={"GPU_MAX_HW_QUEUES": "4"})  # ... also when spelled out
     ddp.check_hw_queues(apart, environ={"GPU_MAX_HW_QUEUES": "8"})   # one rank per GPU: fine
     ddp.check_hw_queues([None, None], environ={"GPU_MAX_HW_QUEUES": "8"})   # CPU ranks
     with pytest.raises(ddp.SharedDeviceQueuesError, match="share one GPU"):

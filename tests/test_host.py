@@ -184,3 +184,52 @@ def test_blocks_tokenizer_wrappers_state_dict_contract():
     enc = BK.TiTokEncoder(cfg)
     with pytest.raises((VitamdError, RuntimeError)):
         enc(torch.zeros(1, 3, 32, 32), torch.zeros(8, 512))
+
+
+def test_gemm_nt_plan_reports_the_dispatch_rule_without_a_gpu():
+    """vitamd_gemm_nt_plan (ABI 8): the kernel form a launch would take - form | rows << 8 - straight from the dispatcher's own rule (plan_single in
+    csrc/gemm_nt.hip executes for real launches too).  No GPU is needed: with no current device the rule assumes 256 CUs."""
+    from vitamd import lib
+    plan = lib.load().vitamd_gemm_nt_plan
+    SMALL, PP, PERS, SEAM, LOADER = 1, 2, 3, 4, 5
+    M = 256 * 197
+    f = lambda *a: (plan(*a) & 0x7f, plan(*a) >> 8)
+    assert f(M, 2304, 768, 2304, 0, 0) == (SEAM, 256)                 # QKV forward: short K loop, 6.9 tiles per CU
+    assert f(M, 3072, 768, 3072, 6, 0) == (SEAM, 256)                 # fc1 + GELU (stored derivative): the table form needs the 256-row ring
+    assert f(M, 3072, 768, 3072, 7, 0) == (SEAM, 256)                 # dgrad-fc2 x gelu'
+    assert f(M, 768, 3072, 768, 0, 0) == (PERS, 320)                  # N = 768: two rounds of 320 rows instead of three of 256
+    assert f(M, 768, 3072, 768, 2, 0) == (PERS, 320)                  # fc2 + fp32 residual
+    assert f(25216, 2304, 768, 2304, 0, 0) == (SEAM, 256)             # batch 128: 891 tiles >= 3 per CU (ADVICE r3: the host pre-filter missed it)
+    assert f(25216, 2304, 768, 2304, 0, 1024) == (PERS, 320)          # code 1024: persistent, no seam form (3 rounds of 320 rows <= 4 of 256)
+    assert f(M, 2304, 768, 2304, 0, 512) == (PP, 256)                 # code 512: one workgroup per tile
+    assert f(M, 768, 3072, 768, 0, 2048) == (LOADER, 256)             # the loader-wave form on request
+    assert plan(M, 768, 192, 768, 0, 2048) == -1                      # ... refused (VITAMD_ERR_SHAPE) for an odd number of K-tiles
+    assert plan(M, 768, 3072, 768, 2, 2048) == -1                     # ... and for the fp32-residual epilogue
+    assert f(300, 200, 64, 200, 5, 0) == (SMALL, 128)
+    assert plan(0, 8, 64, 8, 0, 0) == -1 and plan(M, 768, 3072, 768, 0, 77) == -2 and plan(M, 768, 3072, 768, 9, 0) == -2
+
+
+def test_init_and_compute_fail_loudly_without_a_device():
+    """No GPU in this process: vitamd_init reports a HIP failure instead of crashing, and nothing falls back to the CPU."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a process without a GPU")
+    from vitamd import lib
+    assert lib.load().vitamd_init(-1, None) == 3                      # VITAMD_ERR_LAUNCH
+    assert lib.ERRORS[4].startswith("vitamd_init")
+
+
+def test_two_hip_runtimes_are_detected(tmp_path):
+    """lib.load() scans /proc/self/maps after dlopen: a second libamdhip64 (round 3's `HIP launch failure` when libvitamd.so was loaded before
+    torch) raises instead of failing at the first launch.  Driven here with stub maps files."""
+    from vitamd import lib
+    one = tmp_path / "maps_one"
+    one.write_text("7f00-7f10 r-xp 00000000 fd:01 1 /usr/lib/torch/lib/libamdhip64.so\n"
+                   "7f10-7f20 r--p 00010000 fd:01 1 /usr/lib/torch/lib/libamdhip64.so\n"
+                   "7f20-7f30 r-xp 00000000 fd:01 2 /usr/lib/libc.so.6\n7f30-7f40 rw-p 00000000 00:00 0 \n")
+    assert lib.check_single_hip_runtime(str(one)) == ["/usr/lib/torch/lib/libamdhip64.so"]
+    two = tmp_path / "maps_two"
+    two.write_text(one.read_text() + "7f40-7f50 r-xp 00000000 fd:01 3 /opt/rocm-7.2.0/lib/libamdhip64.so.7.2.0\n")
+    with pytest.raises(lib.VitamdError) as e:
+        lib.check_single_hip_runtime(str(two))
+    assert "/opt/rocm-7.2.0/lib/libamdhip64.so.7.2.0" in str(e.value) and "/usr/lib/torch/lib/libamdhip64.so" in str(e.value)
+    assert len(lib.check_single_hip_runtime()) <= 1                  # this very process: one runtime (torch's), or none mapped yet

@@ -52,7 +52,11 @@ def check_hw_queues(device_ids, environ=None):
     swapped out never gets its signal.  With the default 4 queues per process every queue stays resident and the same rehearsal runs.
     So the combination is an error here, not a warning."""
     environ = os.environ if environ is None else environ
-    if environ.get("GPU_MAX_HW_QUEUES") and ranks_share_device(device_ids):
+    try:
+        raised = int(environ.get("GPU_MAX_HW_QUEUES") or 0) > 4          # the default (4), spelled out, is the configuration that works
+    except ValueError:
+        raised = True
+    if raised and ranks_share_device(device_ids):
         raise SharedDeviceQueuesError(
             f"GPU_MAX_HW_QUEUES={environ['GPU_MAX_HW_QUEUES']} is set and several ranks share one GPU: this configuration hung in round 2 "
             "(oversubscribed hardware queues under cross-stream barrier packets, DESIGN.md section 7).  Unset GPU_MAX_HW_QUEUES "
@@ -77,21 +81,32 @@ def choose_launch_form(device, group=None, measure=None, rows=16384, width=768, 
     if measure is None:
         measure = lambda form: _measure_form(form, torch.device(device), group, rows, width, iters, bucket_mb)   # noqa: E731
     keep = ops.NT_PERSISTENT
-    times = {}
+    times, errors = {}, []
     try:
         for form in (True, False):
             ops.NT_PERSISTENT = form
-            t = torch.tensor([float(measure(form))], dtype=torch.float64)
+            # A measurement that FAILS on one rank (out of memory, a HIP error) must not desynchronise the job: the failing rank feeds +inf into
+            # the SAME two MAX all-reduces every other rank runs, so all ranks see the failure, keep the default together and go on to the next
+            # collective in step (an exception that skipped these all-reduces left the other ranks blocked in them).
+            try:
+                ms = float(measure(form))
+            except Exception as e:          # noqa: BLE001 - any failure of the measurement counts, the decision must still be collective
+                ms = float("inf")
+                errors.append(f"{type(e).__name__}: {e}")
+            t = torch.tensor([ms], dtype=torch.float64)
             if dist.is_initialized() and dist.get_world_size(group) > 1:
                 t = t.to(device) if dist.get_backend(group) == "nccl" else t
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             times[form] = float(t.item())
     finally:
         ops.NT_PERSISTENT = keep
+    if not all(t < float("inf") for t in times.values()):       # some rank could not measure: every rank keeps the default
+        return {"persistent_ms": None, "per_tile_ms": None, "chosen": "persistent" if keep else "per_tile",
+                "source": "default (the measurement failed on a rank)", "errors": errors}
     chosen = select_launch_form(times[True], times[False])
     ops.NT_PERSISTENT = chosen
     return {"persistent_ms": round(times[True], 4), "per_tile_ms": round(times[False], 4), "chosen": "persistent" if chosen else "per_tile",
-            "source": "measured"}
+            "source": "measured", "measured_at": {"rows": rows, "width": width}}
 
 
 def _measure_form(form, device, group, rows, width, iters, bucket_mb):
@@ -252,7 +267,10 @@ class DataParallel(torch.nn.Module):
                     self.launch_form = {"chosen": "persistent" if ops.NT_PERSISTENT else "per_tile", "source": "VITAMD_NT_PERSISTENT"}
                 else:
                     try:
-                        self.launch_form = choose_launch_form(dev0, process_group)
+                        # measured at the wrapped model's own width where it says so (a ViT: .vit.config / .config -> n_embd), else ViT-B's
+                        cfg = getattr(getattr(module, "vit", module), "config", None)
+                        width = int(getattr(getattr(cfg, "trans_config", cfg), "n_embd", 768) or 768)
+                        self.launch_form = choose_launch_form(dev0, process_group, width=width if width % 64 == 0 else 768)
                     except Exception as e:
                         import warnings
                         warnings.warn(f"vitamd.ddp: launch-form measurement failed ({type(e).__name__}: {e}); keeping the default")

@@ -89,6 +89,28 @@ def use_experimental():
     LIB_PATH = EXP_LIB_PATH
 
 
+def hip_runtimes(maps_path="/proc/self/maps"):
+    """The distinct libamdhip64 files mapped into this process (by real path)."""
+    found = set()
+    with open(maps_path) as fh:
+        for line in fh:
+            parts = line.split(None, 5)
+            if len(parts) == 6 and "libamdhip64" in os.path.basename(parts[5].strip()):
+                found.add(os.path.realpath(parts[5].strip()))
+    return sorted(found)
+
+
+def check_single_hip_runtime(maps_path="/proc/self/maps"):
+    """Two HIP runtimes in one process - e.g. /opt/rocm's libamdhip64 pulled in by an early dlopen of libvitamd.so AND the copy a PyTorch wheel
+    bundles - register kernels with one and pass streams and pointers of the other: the first launch fails with `HIP launch failure` (round 3,
+    gpurun_out/r3/smoke_dbg*.log).  Detected here instead of relying on import order: raises VitamdError naming both files."""
+    found = hip_runtimes(maps_path)
+    if len(found) > 1:
+        raise VitamdError("two HIP runtimes are mapped into this process: " + " and ".join(found) + " - libvitamd.so must resolve libamdhip64 to "
+                          "the runtime that owns the caller's streams and pointers (import torch / load the framework BEFORE dlopen-ing libvitamd.so)")
+    return found
+
+
 def load():
     """Load the library (once) and type every entry point.  Raises if it is not built."""
     global _lib
@@ -103,9 +125,11 @@ def load():
     # dependency resolves to the runtime already in the process.
     import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    check_single_hip_runtime()
     if LIB_PATH == EXP_LIB_PATH:
-        lib.vitamd_set_debug.argtypes = [ctypes.c_int]
-        lib.vitamd_set_debug.restype = ctypes.c_int
+        for dbg in (lib.vitamd_set_debug, lib.vitamd_set_debug2):
+            dbg.argtypes = [ctypes.c_int]
+            dbg.restype = ctypes.c_int
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes

@@ -20,11 +20,14 @@ import os as _os
 NT_PERSISTENT = _os.environ.get("VITAMD_NT_PERSISTENT", "1") != "0"
 # The seam form of the persistent NT kernel (csrc/gemm_nt_seam.h) issues its epilogue as a burst of buffer stores from inline asm.  On one box of the
 # pool, round 3 saw buffer stores issued from inside a GEMM run several times slower than anywhere else (profiles/r03/store_trickle_README.md, last
-# row); the form is therefore PROBED once per process and device against the plain persistent form on a QKV-sized problem and switched off where it
-# loses by more than 25 % (VITAMD_NT_SEAM=1 / 0 skips the probe).  NT_SEAM: None = not probed yet.
+# row); the form is therefore PROBED once per process and DEVICE against the plain persistent form on a QKV-sized problem and switched off there if it
+# loses by more than 25 % (VITAMD_NT_SEAM=1 / 0 decides for every device and skips the probe).  Every GELU epilogue reads the same table, so the
+# decision changes timing only, never bits.
 _seam_env = _os.environ.get("VITAMD_NT_SEAM", "auto")
-NT_SEAM = {"1": True, "0": False}.get(_seam_env)
-SEAM_PROBE = {}          # device index -> {"seam_us", "plain_us", "enabled"}
+NT_SEAM = {"1": True, "0": False}.get(_seam_env)      # process-wide override (None = per device, by probe)
+SEAM_PROBE = {}          # device index -> {"seam_us", "plain_us", "enabled"}: the source of truth for the per-device decision
+NT_FORM_SEAM = 4         # include/vitamd.h VITAMD_NT_FORM_SEAM (vitamd_gemm_nt_plan)
+_RAW_AUTO = -1
 LN_EPS = 1e-5
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -89,47 +92,67 @@ def gemm_nt(a, b, epi, *, bias=None, aux=None, out=None, out2=None, colsum=None,
         _need(bias, F32, "bias", 1)
     if epi in (EPI_GELU, EPI_GELU_DG):
         init(a.device)
-    if tile == 0 and not NT_PERSISTENT:
-        tile = 512                      # automatic tile choice, one workgroup per tile
-    elif tile == 0 and K <= 1536 and M * N >= (1 << 26):     # the shapes the seam rule can apply to (cheap pre-filter; the library decides)
-        if NT_SEAM is None:
-            seam_probe(a.device)
-        if not NT_SEAM:
-            tile = 1024                 # persistent launches without the seam form
+    if tile == 0:
+        tile = auto_tile(a.device, M, N, K, epi)
+    elif tile == _RAW_AUTO:             # the library's own automatic choice, no host-side policy (the probe's seam arm)
+        tile = 0
     code = _L().vitamd_gemm_nt_bf16(_p(a), _p(b), _p(out), _p(out2), _p(bias), _p(aux), _p(colsum), M, N, K, N, epi,
                                     n_patches, seq, extra, tile, _stream())
     _lib.check(code, f"gemm_nt[M={M},N={N},K={K},epi={epi}]")
     return (out, out2) if epi in (EPI_GELU, EPI_GELU_DG) else out
 
 
+def seam_enabled(device):
+    """The seam form's switch for `device`: the process-wide override, else this device's probe result, else None (not probed yet)."""
+    if NT_SEAM is not None:
+        return NT_SEAM
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    rec = SEAM_PROBE.get(idx)
+    return None if rec is None else rec["enabled"]
+
+
+def auto_tile(device, M, N, K, epi):
+    """The ABI `tile` code behind tile = 0: 512 (one workgroup per tile) when persistent launches are off; 1024 (persistent, no seam form) on a
+    device whose seam form is switched off - ALWAYS, whatever the shape: the library treats 1024 as plain auto where its seam rule would not
+    apply anyway; 0 otherwise.  The device is probed the first time the library's own rule (vitamd_gemm_nt_plan) would pick the seam form for a
+    launch; never inside a stream capture (the form then stays on, unrecorded, until an eager launch probes)."""
+    if not NT_PERSISTENT:
+        return 512
+    on = seam_enabled(device)
+    if on is None:
+        if _L().vitamd_gemm_nt_plan(M, N, K, N, epi, 0) & 0x7f != NT_FORM_SEAM or torch.cuda.is_current_stream_capturing():
+            return 0
+        on = seam_probe(device)
+    return 0 if on else 1024
+
+
 def seam_probe(device, rows=49152, reps=3):
-    """Time the seam form against the plain persistent form (QKV shape of ViT-B at `rows` rows: 192 x 9 tiles = 6.75 per CU, K = 768; the seam form is worth ~5 % there and costs ~5 % at 3.4 tiles per CU) on `device` and set NT_SEAM.
-    ~3 ms once per process; results kept in SEAM_PROBE."""
-    global NT_SEAM
+    """Time the seam form against the plain persistent form (QKV shape of ViT-B at `rows` rows: 192 x 9 tiles = 6.75 per CU, K = 768; the seam form is worth ~5 % there and costs ~5 % at 3.4 tiles per CU) on `device`; the result is kept per device in SEAM_PROBE.
+    ~3 ms once per process and device."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    NT_SEAM = True                      # (the calls below must not recurse into the probe)
     x = torch.randn(rows, 768, device=device).to(BF16)
     w = torch.randn(2304, 768, device=device).mul_(0.03).to(BF16)
     out = torch.empty((rows, 2304), dtype=BF16, device=device)
     times = {}
-    for name, tile in (("seam_us", 0), ("plain_us", 1024)):
-        gemm_nt(x, w, EPI_BIAS_BF16, out=out, tile=tile)
+    for name, tile in (("seam_us", _RAW_AUTO), ("plain_us", 1024)):
+        launch = lambda: gemm_nt(x, w, EPI_BIAS_BF16, out=out, tile=tile)
+        launch()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(reps):
-            gemm_nt(x, w, EPI_BIAS_BF16, out=out, tile=tile)
+            launch()
         e.record()
         e.synchronize()
         times[name] = s.elapsed_time(e) / reps * 1e3
-    NT_SEAM = times["seam_us"] <= 1.25 * times["plain_us"]           # the probe guards against a pathologically slow store path, not against a 5 % difference
-    SEAM_PROBE[device.index] = {"seam_us": round(times["seam_us"], 1), "plain_us": round(times["plain_us"], 1), "enabled": NT_SEAM}
-    if not NT_SEAM:
+    on = times["seam_us"] <= 1.25 * times["plain_us"]           # the probe guards against a pathologically slow store path, not against a 5 % difference
+    SEAM_PROBE[device.index] = {"seam_us": round(times["seam_us"], 1), "plain_us": round(times["plain_us"], 1), "enabled": on}
+    if not on:
         import warnings
         warnings.warn(f"vitamd: the seam form of the NT GEMM is slower than the plain persistent form on {device} "
-                      f"({times['seam_us']:.0f} vs {times['plain_us']:.0f} us): switched off for this process")
-    return NT_SEAM
+                      f"({times['seam_us']:.0f} vs {times['plain_us']:.0f} us): switched off for this device")
+    return on
 
 
 _WORKSPACES = {}
