@@ -62,43 +62,50 @@ def kernel_roofline(dev):
     b3, b4, b1 = torch.randn(3 * D, device=dev), torch.randn(4 * D, device=dev), torch.randn(D, device=dev)
     res = torch.randn(M, D, device=dev)
     cs = torch.zeros(4 * D, device=dev)
-    nt_calls = [
-        ("qkv", lambda: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3), 2.0 * M * D * 3 * D),
-        ("fc1+gelu", lambda: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4), 2.0 * M * D * 4 * D),
-        ("fc2+resid", lambda: ops.gemm_nt(x4, w2, ops.EPI_RESID_F32, bias=b1, aux=res), 2.0 * M * D * 4 * D),
-        ("dgrad_fc2", lambda: ops.gemm_nt(x1, w2_t, ops.EPI_DMUL, aux=x4, colsum=cs), 2.0 * M * D * 4 * D),
-        ("dgrad_fc1", lambda: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 4 * D),
-        ("dgrad_qkv", lambda: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 3 * D),
+    y2 = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    nt_calls = [       # (name, launch, FLOPs, launches per step): inside the stack fc2 writes bf16 (DEFER_RESID), only the last layer's adds the residual
+        ("qkv", lambda: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3), 2.0 * M * D * 3 * D, 12),
+        ("fc1+gelu", lambda: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4), 2.0 * M * D * 4 * D, 12),
+        ("fc2", lambda: ops.gemm_nt(x4, w2, ops.EPI_BIAS_BF16, bias=b1, out=y2), 2.0 * M * D * 4 * D, 11),
+        ("fc2+resid", lambda: ops.gemm_nt(x4, w2, ops.EPI_RESID_F32, bias=b1, aux=res), 2.0 * M * D * 4 * D, 1),
+        ("dgrad_fc2", lambda: ops.gemm_nt(x1, w2_t, ops.EPI_DMUL, aux=x4, colsum=cs), 2.0 * M * D * 4 * D, 12),
+        ("dgrad_fc1", lambda: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 4 * D, 12),
+        ("dgrad_qkv", lambda: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16), 2.0 * M * D * 3 * D, 12),
     ]
     dWqkv, dW1, dW2 = (torch.empty(s, device=dev) for s in ((3 * D, D), (4 * D, D), (D, 4 * D)))
     tn_calls = [       # split-K factors as the step chooses them (vitamd.functions._tn_splits)
-        ("dW_fc2", lambda: ops.gemm_tn(x1, x4, dW2, accumulate=False, splits=F._tn_splits(dW2), form=F._tn_form("fc2")), 2.0 * M * D * 4 * D),
-        ("dW_fc1", lambda: ops.gemm_tn(x4, x1, dW1, accumulate=False, splits=F._tn_splits(dW1), form=F._tn_form("fc1")), 2.0 * M * D * 4 * D),
-        ("dW_qkv", lambda: ops.gemm_tn(x3, x1, dWqkv, accumulate=False, splits=F._tn_splits(dWqkv), form=F._tn_form("qkv")), 2.0 * M * D * 3 * D),
+        ("dW_fc2", lambda: ops.gemm_tn(x1, x4, dW2, accumulate=False, splits=F._tn_splits(dW2), form=F._tn_form("fc2")), 2.0 * M * D * 4 * D, 12),
+        ("dW_fc1", lambda: ops.gemm_tn(x4, x1, dW1, accumulate=False, splits=F._tn_splits(dW1), form=F._tn_form("fc1")), 2.0 * M * D * 4 * D, 12),
+        ("dW_qkv", lambda: ops.gemm_tn(x3, x1, dWqkv, accumulate=False, splits=F._tn_splits(dWqkv), form=F._tn_form("qkv")), 2.0 * M * D * 3 * D, 12),
     ]
-    prof = pmc_profile()
+    step_table = nt_step_table(M)
+    prof = pmc_profile(step_table)
 
     def family(calls, kernel):
-        # per shape (informational): ten launches back to back; reported: the launches in layer order, eight layers' worth between one pair of events
-        detail = {name: round(flops / sorted(_timed([fn], 5) for _ in range(3))[1] / 1e9, 1) for name, fn, flops in calls}     # median of three 5-launch timings
-        ms = _timed([fn for _, fn, _ in calls], 8)
-        ach = sum(f for _, _, f in calls) / ms / 1e9
+        # per shape (informational): five launches back to back, median of three; reported: ONE STEP's launches of the family in layer order
+        # (12 layers: every call whose per-step count exceeds the layer index) between one pair of events, twice
+        detail = {name: round(flops / sorted(_timed([fn], 5) for _ in range(3))[1] / 1e9, 1) for name, fn, flops, _ in calls}
+        seq = [fn for layer in range(12) for name, fn, _, n in calls if (layer < n if n != 1 else layer == 11)]
+        ms = _timed(seq, 2)
+        flops = sum(f * n for _, _, f, n in calls)
+        ach = flops / ms / 1e9
         return {"kernel": kernel, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "launches_per_layer": len(calls), "avg_launch_us": round(ms * 1e3 / len(calls), 1), "per_shape_tflops": detail,
+                "launches_per_step": len(seq), "avg_launch_us": round(ms * 1e3 / len(seq), 1), "per_shape_tflops": detail,
                 "recorded_mfma_util": (prof.get("mfma_util") or {}).get(kernel), "recorded_traffic": (prof.get("traffic") or {}).get(kernel)}
 
     nt = family(nt_calls, "gemm_nt")          # gemm_nt_pp_kernel and its seam form gemm_nt_seam_kernel
     tn = family(tn_calls, "gemm_tn")          # gemm_tn_pp_kernel (8 waves) and gemm_tn_ld_kernel (12 waves, loader waves)
     # (informational) the same weight-gradient GEMMs cut for the whole chip (252 workgroups) instead of the ~128 the step uses so that
     # they leave half the CUs to the main stream's kernels
-    full = [(n, (lambda l=l, r=r, o=o: ops.gemm_tn(l, r, o, accumulate=False, splits=0)), f) for (n, _, f), (l, r, o) in
+    full = [(n, (lambda l=l, r=r, o=o: ops.gemm_tn(l, r, o, accumulate=False, splits=0)), f) for (n, _, f, _), (l, r, o) in
             zip(tn_calls, ((x1, x4, dW2), (x4, x1, dW1), (x3, x1, dWqkv)))]
     tn["whole_chip_split_per_shape_tflops"] = {name: round(flops / _timed([fn], 10) / 1e9, 1) for name, fn, flops in full}
     # `achieved` / `per_shape_tflops` are measured live in this run.  `recorded_*` and `traffic` are NOT: they come from rocprofv3 PMC passes of
     # this same command committed under profiles/ (collected with --pmc in separate runs, as the guide prescribes), and say so: "static": true;
     # "stale": true when the kernel sources have changed since those passes were made (then `traffic` is null).
     rec_ok = prof.get("source") is not None and not prof.get("stale")
-    out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel + gemm_nt_seam_kernel (320x256x64 / 256x256x64 ping-pong tiles; the 6 NT GEMM launches of one layer)",
+    out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel + gemm_nt_seam_kernel (320x256x64 / 256x256x64 ping-pong tiles; the 72 large NT GEMM launches of one step, in layer order)",
+           "instantiations": step_table,
            "achieved": nt["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": nt["frac"],
            "traffic": (nt["recorded_traffic"] or {}).get("bytes_per_launch") if rec_ok else None,
            "recorded": {"static": True, "stale": bool(prof.get("stale")), "source": prof.get("source"), "made_at": prof.get("meta"),
@@ -110,8 +117,51 @@ def kernel_roofline(dev):
     return out
 
 
-PMC_DIR = os.path.join("profiles", "r03")
-NT_ALGO_MB = (12 * 313 + 12 * 702 + 12 * 702 + 12 * 392 + 12 * 313 + 11 * 392 + 625) / 72.0     # algorithmic MB per launch, weighted over the 72 large NT launches of a step: QKV 313, fc1+GELU 702, dgrad-fc2 702, dgrad-fc1 392, dgrad-QKV 313, fc2 392 (bf16 out; the last layer's fused residual 625)
+PMC_DIR = os.path.join("profiles", "r04")
+
+# The 72 large NT GEMM launches of one training step at the headline config (M = 256 x 197 token rows), as vitamd.functions issues them:
+# (name, ABI epilogue code, N, K, launches per step).  Inside the stack fc2 writes bf16 (the next LayerNorm adds the residual: DEFER_RESID);
+# only the last layer's fc2 carries the fused fp32 residual.
+NT_STEP_LAUNCHES = [("qkv", 0, 2304, 768, 12), ("fc1+gelu", 6, 3072, 768, 12), ("fc2", 0, 768, 3072, 11), ("fc2+resid", 2, 768, 3072, 1),
+                    ("dgrad_fc2", 7, 3072, 768, 12), ("dgrad_fc1", 0, 768, 3072, 12), ("dgrad_qkv", 0, 768, 2304, 12)]
+
+
+def nt_algorithmic_bytes(M, N, K, epi):
+    """Bytes a launch must move once: both operands, the output(s), the epilogue's auxiliary input (SURVEY.md section 8d shapes)."""
+    b = (M * K + N * K) * 2
+    if epi == 2:
+        return b + 2 * M * N * 4            # fp32 residual in, fp32 stream out
+    return b + M * N * 2 * (2 if epi in (1, 6, 3, 7) else 1)      # bf16 out (+ the second GELU output / the dGELU factor)
+
+
+def nt_instantiation(plan, epi):
+    """The kernel instantiation (name as tools/pmc_traffic.py::kernel_key prints it) behind a vitamd_gemm_nt_plan code."""
+    e = {6: 1, 7: 3}.get(epi, epi)
+    form, rows = plan & 0x7f, plan >> 8
+    mt = rows // 32
+    tab = "true" if e == 1 else "false"
+    if form == 5:
+        return f"gemm_nt_ld_kernel<{e}, {tab}, 1>"
+    if form == 4:
+        return f"gemm_nt_seam_kernel<{e}, {mt}, 0, {tab}>"
+    if form in (2, 3):
+        return f"gemm_nt_pp_kernel<{e}, {mt}, 4, 6, {'true' if form == 3 else 'false'}>"
+    return "gemm_nt_kernel<128, 128, 2, 2, %d>" % e
+
+
+def nt_step_table(M=PER_GPU_BATCH * 197):
+    """instantiation -> {launches per step, algorithmic bytes per launch (launch-weighted over the shapes it serves), shapes}: which kernel each
+    launch class takes comes from the library's own dispatch rule (vitamd_gemm_nt_plan), so the table follows the code."""
+    from vitamd import lib
+    plan = lib.load().vitamd_gemm_nt_plan
+    out = {}
+    for name, epi, N, K, n in NT_STEP_LAUNCHES:
+        inst = nt_instantiation(plan(M, N, K, N, epi, 0), epi)
+        rec = out.setdefault(inst, {"launches": 0, "bytes": 0.0, "shapes": []})
+        rec["launches"] += n
+        rec["bytes"] += n * nt_algorithmic_bytes(M, N, K, epi)
+        rec["shapes"].append(name)
+    return {k: {"launches_per_step": v["launches"], "algorithmic_bytes_per_launch": int(v["bytes"] / v["launches"]), "shapes": v["shapes"]} for k, v in out.items()}
 
 
 def csrc_sha16():
@@ -123,7 +173,7 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_profile():
+def pmc_profile(step_table=None):
     """Per-kernel MFMA utilisation and HBM bytes per launch RECORDED by rocprofv3 PMC passes of this bench command and committed under
     profiles/ (final_pmc_mfma.json: tools/pmc_mfma.py; final_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes folded by
     tools/pmc_traffic.py with the gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE; final_pmc_meta.json: the source hash they were made at).
@@ -139,7 +189,7 @@ def pmc_profile():
         mf = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_mfma.json")))
         util = {}
         for fam in ("gemm_nt", "gemm_tn"):
-            sel = {k: v for k, v in mf.items() if (("gemm_nt_pp_kernel" in k or "gemm_nt_seam_kernel" in k) if fam == "gemm_nt" else ("gemm_tn_pp_kernel" in k or "gemm_tn_ld_kernel" in k)) and v["avg_us_profiled"] > 50}
+            sel = {k: v for k, v in mf.items() if (("gemm_nt_pp_kernel" in k or "gemm_nt_seam_kernel" in k or "gemm_nt_ld_kernel" in k) if fam == "gemm_nt" else ("gemm_tn_pp_kernel" in k or "gemm_tn_ld_kernel" in k)) and v["avg_us_profiled"] > 50}
             rows = [(v["launches"], v["avg_us_profiled"], v["mfma_util"]) for v in sel.values()]
             if rows:       # time-weighted over the family's launches
                 util[fam] = {"mfma_busy_frac": round(sum(n * t * u for n, t, u in rows) / sum(n * t for n, t, _ in rows), 4),
@@ -150,20 +200,72 @@ def pmc_profile():
         pass
     try:
         tr = json.load(open(os.path.join(ROOT, PMC_DIR, "final_pmc_hbm_traffic.json")))
+        key = "hbm_MB_avg_corrected(2*fetch+write)"
         traffic = {}
-        nt = [v for k, v in tr.items() if ("gemm_nt_pp_kernel<" in k or "gemm_nt_seam_kernel<" in k) and v["launches"] >= 12]
-        if nt:
-            tot_n = sum(v["launches"] for v in nt)
-            mb = sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in nt) / tot_n
-            traffic["gemm_nt"] = {"bytes_per_launch": int(mb * 1e6), "algorithmic_bytes_per_launch": int(NT_ALGO_MB * 1e6)}
-        tn = [v for k, v in tr.items() if "gemm_tn_pp_kernel<" in k or "gemm_tn_ld_kernel<" in k]
+        # NT family: every instantiation the step launches, each against ITS OWN algorithmic bytes; the family figure weights them by launches per step
+        per, tot_n, tot_b, tot_a = {}, 0, 0.0, 0.0
+        for inst, rec in (step_table if step_table is not None else nt_step_table()).items():
+            if inst not in tr:
+                continue
+            meas, algo, n = tr[inst][key] * 1e6, rec["algorithmic_bytes_per_launch"], rec["launches_per_step"]
+            per[inst] = {"bytes": int(meas), "algorithmic": algo, "ratio": round(meas / algo, 3), "launches_per_step": n, "shapes": rec["shapes"]}
+            tot_n += n; tot_b += n * meas; tot_a += n * algo
+        if tot_n:
+            traffic["gemm_nt"] = {"bytes_per_launch": int(tot_b / tot_n), "algorithmic_bytes_per_launch": int(tot_a / tot_n),
+                                  "ratio": round(tot_b / tot_a, 3), "launches_covered": tot_n, "per_instantiation": per}
+        tn = [v for k, v in tr.items() if k.startswith("gemm_tn_pp_kernel<") or k.startswith("gemm_tn_ld_kernel<")]
         if tn:
             tot_n = sum(v["launches"] for v in tn)
-            traffic["gemm_tn"] = {"bytes_per_launch": int(sum(v["launches"] * v["hbm_MB_avg_corrected(2*fetch+write)"] for v in tn) / tot_n * 1e6),
-                                            "algorithmic_bytes_per_launch": int((387 + 387 + 309) / 3 * 1e6 + 9.4e6)}
+            traffic["gemm_tn"] = {"bytes_per_launch": int(sum(v["launches"] * v[key] for v in tn) / tot_n * 1e6),
+                                  "algorithmic_bytes_per_launch": int((387 + 387 + 309) / 3 * 1e6 + 9.4e6)}
         out["traffic"] = traffic
     except Exception:
         pass
+    return out
+
+
+def box_identity(dev):
+    """What identifies the device a line was measured on, so that an outlier box (round 3 met one whose in-GEMM buffer stores ran 4x slower,
+    profiles/r03/store_trickle_README.md) is visible in BENCH_r*.json: architecture, CU count, the clock attributes HIP reports, memory size."""
+    p = torch.cuda.get_device_properties(dev)
+    out = {"name": p.name, "gcnArchName": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+           "total_memory_GiB": round(p.total_memory / 2**30, 1), "l2_cache_MiB": round(getattr(p, "L2_cache_size", 0) / 2**20, 1)}
+    for k in ("clock_rate", "memory_clock_rate", "memory_bus_width"):       # kHz / kHz / bits where torch exposes them
+        if hasattr(p, k):
+            out[k] = getattr(p, k)
+    out["hip"] = getattr(torch.version, "hip", None)
+    return out
+
+
+def also_models(dev):
+    """Driver-visible numbers for BASELINE configs[3] / configs[4]: forward + backward (MSE + quantiser loss; the perceptual term
+    needs downloaded ConvNeXt weights and stays out) of TiTok-S (train_titok.py:79-93) and ViT-VQGAN-B (train_vit_vqgan.py:34-91) on this GPU,
+    3 warm-up + 5 timed steps each, after the headline timing; not part of `value`."""
+    import train_titok as TT, train_vit_vqgan as TQ
+    from vitamd.functions import WEIGHTS
+    out = {}
+    for key, make, bs in (("titok_s256", lambda: TT.TiTok(TT.TiTokConfig(256, 16, 32, 2048, 12, "S")), 256),
+                          ("vitvqgan_b256", lambda: TQ.ViTVQGAN(TQ.ViTVQGANConfig(256, 16, 2048, 12, "B")), 128)):
+        torch.manual_seed(0)
+        model = make().to(dev)
+        x = torch.rand(bs, 3, 256, 256, device=dev)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            WEIGHTS.clear()
+            recon, _idx, ql = model(x)
+            (torch.nn.functional.mse_loss(recon, x) + ql).backward()
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        out[key] = {"img_s": round(bs / dt, 1), "batch": bs, "ms_per_step": round(dt * 1e3, 2), "what": "forward + backward, MSE + quantiser loss, 256x256, bf16 kernels"}
+        del model, x
     return out
 
 
@@ -236,6 +338,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the TiTok-S / ViT-VQGAN-B side measurements")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -337,6 +440,9 @@ def main():
             "final_loss": round(loss_val, 4), "dist": dist_info,
             "nt_seam_probe": __import__("vitamd.ops", fromlist=["SEAM_PROBE"]).SEAM_PROBE.get(dev.index),     # start-up A/B of the seam form on this device (vitamd.ops.seam_probe)
         }
+        out["device"] = box_identity(dev)
+        if world == 1 and not args.no_also:
+            out["also"] = also_models(dev)
         if not args.no_roofline:
             out["roofline"] = kernel_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -233,3 +233,58 @@ def test_two_hip_runtimes_are_detected(tmp_path):
         lib.check_single_hip_runtime(str(two))
     assert "/opt/rocm-7.2.0/lib/libamdhip64.so.7.2.0" in str(e.value) and "/usr/lib/torch/lib/libamdhip64.so" in str(e.value)
     assert len(lib.check_single_hip_runtime()) <= 1                  # this very process: one runtime (torch's), or none mapped yet
+
+
+def test_pmc_traffic_keeps_template_instantiations_apart_and_bench_weights_them(tmp_path, monkeypatch):
+    """VERDICT r3 item 2.  tools/pmc_traffic.py keys kernels by the full name up to the parameter list (round 3 cut at 60 characters and folded
+    gemm_nt_seam_kernel<0|1|3, ...> into one entry); bench.pmc_profile sets every instantiation of the step against ITS OWN algorithmic bytes
+    and reports the launch-weighted family figure.  Driven with a synthetic pair of rocprofv3 counter_collection.csv passes."""
+    import csv
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    import pmc_traffic
+    import bench
+    ns = "(anonymous namespace)::"
+    table = bench.nt_step_table()
+    assert set(table) == {"gemm_nt_seam_kernel<0, 8, 0, false>", "gemm_nt_seam_kernel<1, 8, 0, true>", "gemm_nt_seam_kernel<3, 8, 0, false>",
+                          "gemm_nt_pp_kernel<0, 10, 4, 6, true>", "gemm_nt_pp_kernel<2, 10, 4, 6, true>"}
+    assert sum(v["launches_per_step"] for v in table.values()) == 72
+    M = 256 * 197
+    fc2, dqkv = bench.nt_algorithmic_bytes(M, 768, 3072, 0), bench.nt_algorithmic_bytes(M, 768, 2304, 0)
+    assert (fc2, dqkv) == ((M * 3072 + 768 * 3072 + M * 768) * 2, (M * 2304 + 768 * 2304 + M * 768) * 2)
+    assert table["gemm_nt_pp_kernel<0, 10, 4, 6, true>"]["algorithmic_bytes_per_launch"] == (23 * fc2 + 12 * dqkv) // 35
+    ratio = {"gemm_nt_seam_kernel<0, 8, 0, false>": 1.8, "gemm_nt_seam_kernel<1, 8, 0, true>": 1.5, "gemm_nt_seam_kernel<3, 8, 0, false>": 1.6,
+             "gemm_nt_pp_kernel<0, 10, 4, 6, true>": 1.25, "gemm_nt_pp_kernel<2, 10, 4, 6, true>": 1.2}
+    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        d = tmp_path / "csv" / sub
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            i = 0
+            for inst, r in ratio.items():
+                full = f"void {ns}{ns if 'seam' in inst else ''}{inst}({ns if 'seam' in inst else ''}GemmNtArgs)"
+                assert len(full) > 60
+                total_kb = r * table[inst]["algorithmic_bytes_per_launch"] / 1024
+                kb = total_kb / 4 if counter == "FETCH_SIZE" else total_kb / 2            # 2 x fetch + write = total
+                for _ in range(3):
+                    i += 1
+                    w.writerow([i, full, counter, kb])
+            w.writerow([i + 1, f"{ns}splitk_reduce_kernel(float const*, float*, int, int, int, int, int, int, int)", counter, 100.0])
+    folded = pmc_traffic.fold(str(tmp_path / "csv"))
+    assert set(ratio) <= set(folded) and "splitk_reduce_kernel" in folded and folded["gemm_nt_seam_kernel<1, 8, 0, true>"]["launches"] == 3
+    out = tmp_path / "prof"
+    out.mkdir()
+    json.dump(folded, open(out / "final_pmc_hbm_traffic.json", "w"))
+    json.dump({"csrc_sha16": bench.csrc_sha16()}, open(out / "final_pmc_meta.json", "w"))
+    monkeypatch.setattr(bench, "PMC_DIR", str(out))
+    prof = bench.pmc_profile(table)
+    assert prof["stale"] is False
+    nt = prof["traffic"]["gemm_nt"]
+    assert nt["launches_covered"] == 72 and set(nt["per_instantiation"]) == set(ratio)
+    for inst, r in ratio.items():
+        assert abs(nt["per_instantiation"][inst]["ratio"] - r) < 2e-3
+    want = sum(r * table[i]["algorithmic_bytes_per_launch"] * table[i]["launches_per_step"] for i, r in ratio.items()) / 72
+    assert abs(nt["bytes_per_launch"] - want) / want < 1e-3 and nt["bytes_per_launch"] > nt["algorithmic_bytes_per_launch"]

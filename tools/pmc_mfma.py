@@ -8,6 +8,8 @@ SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE) of the bench command into a per-kernel table
 usage: pmc_mfma.py <dir with *counter_collection.csv> <out.json>"""
 import csv, glob, json, os, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic import kernel_key          # full name up to the parameter list: template instantiations stay apart
 
 src, out = sys.argv[1], sys.argv[2]
 disp = defaultdict(dict)
@@ -21,7 +23,7 @@ for path in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recurs
             d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
 acc = defaultdict(lambda: defaultdict(float))
 for d in disp.values():
-    a = acc[d["name"][:90]]
+    a = acc[kernel_key(d["name"])]
     a["launches"] += 1
     for k, v in d.items():
         if k not in ("name",):
