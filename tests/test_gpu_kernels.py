@@ -275,7 +275,8 @@ def test_seam_probe_and_tile_code_1024(hip):
         assert torch.equal(y0, ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias, tile=1024))
         assert torch.equal(y0, ops.gemm_nt(a, b, ops.EPI_BIAS_BF16, bias=bias, tile=512))
         plan = lib.load().vitamd_gemm_nt_plan
-        assert plan(25216, 2304, 768, 2304, ops.EPI_BIAS_BF16, 0) & 0x7f == ops.NT_FORM_SEAM          # the library's own rule: the seam kernel
+        assert plan(25216, 2304, 768, 2304, ops.EPI_BIAS_BF16, 0) & 0x7f == ops.NT_FORM_LOADER        # the library's own rule: the loader-wave form (an odd number of K-tiles: the seam kernel)
+        assert plan(25216, 2304, 704, 2304, ops.EPI_BIAS_BF16, 0) & 0x7f == ops.NT_FORM_SEAM
         ops.SEAM_PROBE[idx] = dict(rec, enabled=False)               # switched off on this device
         assert ops.auto_tile(dev(), 25216, 2304, 768, ops.EPI_BIAS_BF16) == 1024 and ops.auto_tile(dev(), 512, 512, 64, ops.EPI_F32) == 1024
         assert plan(25216, 2304, 768, 2304, ops.EPI_BIAS_BF16, 1024) & 0x7f == 3                      # VITAMD_NT_FORM_PP_PERSISTENT

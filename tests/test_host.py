@@ -194,12 +194,13 @@ def test_gemm_nt_plan_reports_the_dispatch_rule_without_a_gpu():
     SMALL, PP, PERS, SEAM, LOADER = 1, 2, 3, 4, 5
     M = 256 * 197
     f = lambda *a: (plan(*a) & 0x7f, plan(*a) >> 8)
-    assert f(M, 2304, 768, 2304, 0, 0) == (SEAM, 256)                 # QKV forward: short K loop, 6.9 tiles per CU
-    assert f(M, 3072, 768, 3072, 6, 0) == (SEAM, 256)                 # fc1 + GELU (stored derivative): the table form needs the 256-row ring
-    assert f(M, 3072, 768, 3072, 7, 0) == (SEAM, 256)                 # dgrad-fc2 x gelu'
+    assert f(M, 2304, 768, 2304, 0, 0) == (LOADER, 256)               # QKV forward: short K loop, 6.9 tiles per CU: the loader-wave form (round 4)
+    assert f(M, 3072, 768, 3072, 6, 0) == (LOADER, 256)               # fc1 + GELU (stored derivative), table in LDS
+    assert f(M, 3072, 768, 3072, 7, 0) == (LOADER, 256)               # dgrad-fc2 x gelu'
+    assert f(M, 2304, 704, 2304, 0, 0) == (SEAM, 256)                 # an odd number of K-tiles: the seam kernel
     assert f(M, 768, 3072, 768, 0, 0) == (PERS, 320)                  # N = 768: two rounds of 320 rows instead of three of 256
     assert f(M, 768, 3072, 768, 2, 0) == (PERS, 320)                  # fc2 + fp32 residual
-    assert f(25216, 2304, 768, 2304, 0, 0) == (SEAM, 256)             # batch 128: 891 tiles >= 3 per CU (the host pre-filter missed it)
+    assert f(25216, 2304, 768, 2304, 0, 0) == (LOADER, 256)           # batch 128: 891 tiles >= 3 per CU (the host pre-filter missed it)
     assert f(25216, 2304, 768, 2304, 0, 1024) == (PERS, 320)          # code 1024: persistent, no seam form (3 rounds of 320 rows <= 4 of 256)
     assert f(M, 2304, 768, 2304, 0, 512) == (PP, 256)                 # code 512: one workgroup per tile
     assert f(M, 768, 3072, 768, 0, 2048) == (LOADER, 256)             # the loader-wave form on request
@@ -248,14 +249,14 @@ def test_pmc_traffic_keeps_template_instantiations_apart_and_bench_weights_them(
     import bench
     ns = "(anonymous namespace)::"
     table = bench.nt_step_table()
-    assert set(table) == {"gemm_nt_seam_kernel<0, 8, 0, false>", "gemm_nt_seam_kernel<1, 8, 0, true>", "gemm_nt_seam_kernel<3, 8, 0, false>",
+    assert set(table) == {"gemm_nt_ld_kernel<0, false, 1>", "gemm_nt_ld_kernel<1, true, 1>", "gemm_nt_ld_kernel<3, false, 1>",
                           "gemm_nt_pp_kernel<0, 10, 4, 6, true>", "gemm_nt_pp_kernel<2, 10, 4, 6, true>"}
     assert sum(v["launches_per_step"] for v in table.values()) == 72
     M = 256 * 197
     fc2, dqkv = bench.nt_algorithmic_bytes(M, 768, 3072, 0), bench.nt_algorithmic_bytes(M, 768, 2304, 0)
     assert (fc2, dqkv) == ((M * 3072 + 768 * 3072 + M * 768) * 2, (M * 2304 + 768 * 2304 + M * 768) * 2)
     assert table["gemm_nt_pp_kernel<0, 10, 4, 6, true>"]["algorithmic_bytes_per_launch"] == (23 * fc2 + 12 * dqkv) // 35
-    ratio = {"gemm_nt_seam_kernel<0, 8, 0, false>": 1.8, "gemm_nt_seam_kernel<1, 8, 0, true>": 1.5, "gemm_nt_seam_kernel<3, 8, 0, false>": 1.6,
+    ratio = {"gemm_nt_ld_kernel<0, false, 1>": 1.8, "gemm_nt_ld_kernel<1, true, 1>": 1.5, "gemm_nt_ld_kernel<3, false, 1>": 1.6,
              "gemm_nt_pp_kernel<0, 10, 4, 6, true>": 1.25, "gemm_nt_pp_kernel<2, 10, 4, 6, true>": 1.2}
     for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         d = tmp_path / "csv" / sub
@@ -265,7 +266,7 @@ def test_pmc_traffic_keeps_template_instantiations_apart_and_bench_weights_them(
             w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
             i = 0
             for inst, r in ratio.items():
-                full = f"void {ns}{ns if 'seam' in inst else ''}{inst}({ns if 'seam' in inst else ''}GemmNtArgs)"
+                full = f"void {ns}{ns if '_ld_' in inst else ''}{inst}({ns if '_ld_' in inst else ''}GemmNtArgs)"
                 assert len(full) > 60
                 total_kb = r * table[inst]["algorithmic_bytes_per_launch"] / 1024
                 kb = total_kb / 4 if counter == "FETCH_SIZE" else total_kb / 2            # 2 x fetch + write = total
@@ -274,7 +275,7 @@ def test_pmc_traffic_keeps_template_instantiations_apart_and_bench_weights_them(
                     w.writerow([i, full, counter, kb])
             w.writerow([i + 1, f"{ns}splitk_reduce_kernel(float const*, float*, int, int, int, int, int, int, int)", counter, 100.0])
     folded = pmc_traffic.fold(str(tmp_path / "csv"))
-    assert set(ratio) <= set(folded) and "splitk_reduce_kernel" in folded and folded["gemm_nt_seam_kernel<1, 8, 0, true>"]["launches"] == 3
+    assert set(ratio) <= set(folded) and "splitk_reduce_kernel" in folded and folded["gemm_nt_ld_kernel<1, true, 1>"]["launches"] == 3
     out = tmp_path / "prof"
     out.mkdir()
     json.dump(folded, open(out / "final_pmc_hbm_traffic.json", "w"))

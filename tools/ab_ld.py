@@ -7,7 +7,8 @@ import train_vit as TV
 from vitamd import functions as F, lib
 lib.use_experimental(); L = lib.load(); L.vitamd_set_debug2.argtypes = [ctypes.c_int]
 if os.environ.get("AB_NO_SIDE") == "1": F.SIDE.enabled = False
-cfgs = {"production": 0, "ld_qkv": 1, "ld_gelu": 2, "ld_dgelu": 4, "ld_n768": 8, "ld_qkv+dgelu": 5, "ld_qkv+gelu+dgelu": 7, "ld_all": 15}
+# the defaults since round 4: loader form ON for the three short-K classes (bits 0-2 flip them OFF), TN loader requests split (bit 6 = round-3 loaders); bit 7 (timing only): no split-K reduce pass
+cfgs = {"production": 0, "seam_qkv": 1, "seam_gelu": 2, "seam_dgelu": 4, "seam_all(r3)": 7, "ld_n768_too": 8, "ld_dgrads768_too": 32, "tn_r3_loaders": 64, "no_splitk_reduce(!)": 128}
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = TV.ViTClassifier(TV.ViTConfig(224, 3, 16, "B", 1, 0.0)).to(dev)

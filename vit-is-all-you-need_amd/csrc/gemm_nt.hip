@@ -447,20 +447,21 @@ int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
 enum NtForm { NT_FORM_SMALL = 1, NT_FORM_PP = 2, NT_FORM_PP_PERSISTENT = 3, NT_FORM_SEAM = 4, NT_FORM_LOADER = 5 };
 struct NtPlan { int form, rows, err; };
 
-// The loader-wave form (gemm_nt_ld.h) in the automatic choice: see LD_AUTO in DESIGN.md section 4.7 for the measurements behind the rule.
-static bool ld_auto(const GemmNtArgs& p, long big_tiles, int cus) {
+// The loader-wave form (gemm_nt_ld.h) in the automatic choice.  Measured (profiles/r04/ab_nt_loader_whole_step*.log, two boxes,
+// bit-identical losses): in place of the 256-row seam kernel on the three K = 768 launch classes of a layer (QKV, fc1 + GELU, dgrad-fc2 x gelu') the
+// whole step gains 0.11 / 0.26 ms; on the N = 768 GEMMs (K = 2304 / 3072) it loses - 591 tiles of 256 rows are three rounds of the 256 CUs where
+// gemm_nt_pp_kernel runs two rounds of 320-row tiles, and twelve waves at <= 168 registers cannot hold a 320-row accumulator tile - so those stay.
+// `short_k`: the launch meets the 256-row seam rule (K <= 1536, >= 3 tiles per CU).
+static bool ld_auto(const GemmNtArgs& p, bool short_k) {
+  bool on = short_k;
 #ifdef VITAMD_EXPERIMENTAL
-  // whole-step A/B (tools/ab_ld.py; a debug word of its own, vitamd_set_debug2): bit 0 = plain-bias launches with a short K loop (QKV), 1 = GELU,
-  // 2 = dGELU-multiply, 3 = plain-bias launches with a long K loop (the N = 768 GEMMs: three rounds of 256-row tiles where gemm_nt_pp_kernel runs
-  // two of 320 rows)
+  // whole-step A/B (tools/ab_ld.py; vitamd_set_debug2): bits 0 / 1 / 2 FLIP the default for plain-bias / GELU / dGELU-multiply launches with a short K
+  // loop; bit 3 = also the plain-bias launches with a long K loop (the N = 768 GEMMs), bit 5 = those of them without a bias (the input-gradient GEMMs)
   const int d = g_vitamd_debug2;
-  if (p.epi == EPI_BIAS_BF16 && p.K <= 1536 && big_tiles >= 3L * cus) return (d & 1) != 0;
-  if (p.epi == EPI_GELU && p.K <= 1536 && big_tiles >= 3L * cus) return (d & 2) != 0;
-  if (p.epi == EPI_DGELU && p.K <= 1536 && big_tiles >= 3L * cus) return (d & 4) != 0;
-  if (p.epi == EPI_BIAS_BF16 && p.K > 1536) return (d & 8) != 0;
+  if (short_k) on = on != ((d & (p.epi == EPI_BIAS_BF16 ? 1 : p.epi == EPI_GELU ? 2 : 4)) != 0);
+  else if (p.epi == EPI_BIAS_BF16 && p.K > 1536) on = (d & 8) != 0 || ((d & 32) != 0 && !p.bias);
 #endif
-  (void)p; (void)big_tiles; (void)cus;
-  return false;
+  return on;
 }
 
 static NtPlan plan_single(const GemmNtArgs& p) {
@@ -488,11 +489,12 @@ static NtPlan plan_single(const GemmNtArgs& p) {
     // 4 % slower where a CU sees only two tiles of a long K loop (dgrad-fc1 K = 3072, dgrad-QKV K = 2304), which therefore stay on the form
     // below.  Bit-identical results.  (dbg bit 17: off)
     if (seam_epi && !no_seam && seam_ok(p)) {
-      if (ld_ok(p) && ld_auto(p, big_tiles, cus)) return NtPlan{NT_FORM_LOADER, 256, VITAMD_OK};
       if (p.K <= 1536 && !(VITAMD_DBG(p) & 0x20000)) {
         if (epi == EPI_BIAS_BF16 && tall && (long)((p.M + 319) / 320) * ((p.N + 255) / 256) >= 3L * cus) return NtPlan{NT_FORM_SEAM, 320, VITAMD_OK};
-        if (big_tiles >= 3L * cus) return NtPlan{NT_FORM_SEAM, 256, VITAMD_OK};
+        // 256-row tiles: the loader-wave form (gemm_nt_ld.h) where it applies (an even number of K-tiles), else the seam kernel
+        if (big_tiles >= 3L * cus) return NtPlan{ld_ok(p) && ld_auto(p, true) ? NT_FORM_LOADER : NT_FORM_SEAM, 256, VITAMD_OK};
       }
+      if (ld_ok(p) && ld_auto(p, false)) return NtPlan{NT_FORM_LOADER, 256, VITAMD_OK};
     }
     return NtPlan{NT_FORM_PP_PERSISTENT, tall ? 320 : 256, VITAMD_OK};
   }

@@ -202,7 +202,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_pp_kernel(const GemmTnArgs a,
 // Measured (tools/bench_tn.py, profiles/r03/tn_loader_waves.log): alone 171 / 214 / 216 us against 201 / 247 / 258 for the three ViT-B weight
 // gradients (-15 %); inside the step it wins where the launch runs beside kernels that fill their CUs anyway (the fc2 weight gradient, beside
 // the two input-gradient GEMMs: -0.1 ... -0.36 ms per step) and loses where the 8-wave form shared CUs with LayerNorm (all launches: +0.46 ms).
-template <int NQ, int D, int ABL = 0>      // ABL (experimental builds, timing only, results are garbage): 1 = no MFMAs, 2 = no transposed LDS reads, 3 = neither
+// LSPLIT (round 4, from the NT loader kernel where it was worth 5-14 %): the loaders issue half of a quarter's four requests behind the phase's
+// first barrier instead of all four in front of it, and run at priority 3 - a loader that is late for a barrier holds up all twelve waves.
+template <int NQ, int D, int ABL = 0, bool LSPLIT = true>      // ABL (experimental builds, timing only, results are garbage): 1 = no MFMAs, 2 = no transposed LDS reads, 3 = neither
 __global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int tiles_p, int tiles_q, int splits) {
   static_assert(D >= 2 && D <= NQ - 2, "prefetch distance: WAR rule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,22 +235,33 @@ __global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int
     const unsigned dstL = lds_addr(smem) + l * 2048, dstR = dstL + 8192;
     unsigned soL = (unsigned)g_lo * qbL, soR = (unsigned)g_lo * qbR;
     int slot_w = 0;
-    auto issue = [&]() {
+    auto issue_l = [&]() {
       const unsigned o = slot_w * QSLOT;
       asm_glds16(srdL, dstL + o, voffL[0], soL);
       asm_glds16(srdL, dstL + o + 1024, voffL[1], soL);
+    };
+    auto issue_r = [&]() {
+      const unsigned o = slot_w * QSLOT;
       asm_glds16(srdR, dstR + o, voffR[0], soR);
       asm_glds16(srdR, dstR + o + 1024, voffR[1], soR);
       soL += qbL; soR += qbR;
       slot_w = slot_w + 1 == NQ ? 0 : slot_w + 1;
     };
+    auto issue = [&]() { issue_l(); issue_r(); };
+    if constexpr (LSPLIT) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int d = 0; d < D; ++d) issue();
     VITAMD_WAIT_VM(4 * (D - 1));
     __builtin_amdgcn_s_barrier();
     for (int g = g_lo; g < g_hi; ++g) {
+      if constexpr (LSPLIT) {
+        issue_l();
+        __builtin_amdgcn_s_barrier();
+        issue_r();
+      } else {
       issue();
       __builtin_amdgcn_s_barrier();
+      }
       // quarter g + 1 is first read by the first wave row BEHIND the second barrier of this iteration, so the wait may sit here rather than in
       // front of the first barrier (one more interval for the requests to land).  Measured equal (164 / 212 / 215 us either way).
       VITAMD_WAIT_VM(4 * (D - 1));
@@ -460,13 +473,24 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
       } else
 #endif
       {
+#ifdef VITAMD_EXPERIMENTAL
+      if (g_vitamd_debug2 & 64) {                    // A/B (vitamd_set_debug2 bit 6): the round-3 loaders (all four requests in front of the first barrier, priority 0)
+        if (int e = set_lds((gemm_tn_ld_kernel<8, 4, 0, false>), lds)) return e;
+        hipLaunchKernelGGL((gemm_tn_ld_kernel<8, 4, 0, false>), grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
+      } else
+#endif
+      {
       if (int e = set_lds(gemm_tn_ld_kernel<8, 4>, lds)) return e;
       hipLaunchKernelGGL((gemm_tn_ld_kernel<8, 4>), grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
+      }
       }
     } else {
     if (int e = set_lds(gemm_tn_pp_kernel<true, 8, 4>, lds)) return e;
     hipLaunchKernelGGL((gemm_tn_pp_kernel<true, 8, 4>), grid, block, lds, stream, a, tiles_p, tiles_q, splits);
     }
+#ifdef VITAMD_EXPERIMENTAL
+    if (!(g_vitamd_debug2 & 128))                    // (vitamd_set_debug2 bit 7, timing only, gradients garbage: NO reduce pass - the bound on what folding / batching it could gain)
+#endif
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits,
                        a.accumulate);
   } else {

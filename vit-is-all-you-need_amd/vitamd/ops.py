@@ -26,7 +26,7 @@ NT_PERSISTENT = _os.environ.get("VITAMD_NT_PERSISTENT", "1") != "0"
 _seam_env = _os.environ.get("VITAMD_NT_SEAM", "auto")
 NT_SEAM = {"1": True, "0": False}.get(_seam_env)      # process-wide override (None = per device, by probe)
 SEAM_PROBE = {}          # device index -> {"seam_us", "plain_us", "enabled"}: the source of truth for the per-device decision
-NT_FORM_SEAM = 4         # include/vitamd.h VITAMD_NT_FORM_SEAM (vitamd_gemm_nt_plan)
+NT_FORM_SEAM, NT_FORM_LOADER = 4, 5         # include/vitamd.h VITAMD_NT_FORM_* (vitamd_gemm_nt_plan): the two forms whose epilogue is a burst of asm buffer stores
 _RAW_AUTO = -1
 LN_EPS = 1e-5
 BF16, F32 = torch.bfloat16, torch.float32
@@ -113,14 +113,14 @@ def seam_enabled(device):
 
 def auto_tile(device, M, N, K, epi):
     """The ABI `tile` code behind tile = 0: 512 (one workgroup per tile) when persistent launches are off; 1024 (persistent, no seam form) on a
-    device whose seam form is switched off - ALWAYS, whatever the shape: the library treats 1024 as plain auto where its seam rule would not
-    apply anyway; 0 otherwise.  The device is probed the first time the library's own rule (vitamd_gemm_nt_plan) would pick the seam form for a
+    device whose seam / loader forms are switched off - ALWAYS, whatever the shape: the library treats 1024 as plain auto where its seam rule would not
+    apply anyway; 0 otherwise.  The device is probed the first time the library's own rule (vitamd_gemm_nt_plan) would pick the seam or the loader form for a
     launch; never inside a stream capture (the form then stays on, unrecorded, until an eager launch probes)."""
     if not NT_PERSISTENT:
         return 512
     on = seam_enabled(device)
     if on is None:
-        if _L().vitamd_gemm_nt_plan(M, N, K, N, epi, 0) & 0x7f != NT_FORM_SEAM or torch.cuda.is_current_stream_capturing():
+        if _L().vitamd_gemm_nt_plan(M, N, K, N, epi, 0) & 0x7f not in (NT_FORM_SEAM, NT_FORM_LOADER) or torch.cuda.is_current_stream_capturing():
             return 0
         on = seam_probe(device)
     return 0 if on else 1024
