@@ -419,9 +419,9 @@ def test_gemm_tn_overwrite_mode_without_workspace_is_refused(hip):
 
 
 def test_experimental_library_alternatives(hip):
-    """The measured alternative kernels live in libvitamd_exp.so (make EXPERIMENTAL=1), not in the product.  Their exactness checks
-    (tools/check_experimental.py: NT pipe / persistent / ring / deep kernels, TN round-1 / 16x16x32 / wide kernels, fused attention
-    backward) run in a child process so that this process only ever maps the production library."""
+    """What libvitamd_exp.so (make EXPERIMENTAL=1) carries beyond the product - explicit seam-kernel codes, the loader kernel's first request
+    schedule, the round-3 weight-gradient loaders, the split-role and plain-loop attention backward - is checked bit for bit against production by
+    tools/check_experimental.py, in a child process so that this process only ever maps the production library."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "vit-is-all-you-need_amd", "vitamd", "libvitamd_exp.so")):

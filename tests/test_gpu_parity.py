@@ -260,7 +260,7 @@ def test_tokenizer_vs_reference_golden(hip, name):
             continue
         assert torch.isfinite(p.grad).all(), k
         e = _err(p.grad, ref)
-        if e > 3 * floor["grads"][k] + 2e-2:
+        if e > 2 * floor["grads"][k] + 1e-2:          # (round 4: tightened from 3 x floor + 2e-2; worst measured 5.2e-2 where the reference's own autocast floor is 3.6e-2)
             bad.append((k, round(e, 4), round(floor["grads"][k], 4)))
     assert not bad, bad[:8]
 

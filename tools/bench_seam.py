@@ -17,13 +17,13 @@ wqkv, w1, w2 = rb(3 * D, D, scale=0.03), rb(4 * D, D, scale=0.03), rb(D, 4 * D, 
 wqkv_t, w1_t, w2_t = rb(D, 3 * D, scale=0.03), rb(D, 4 * D, scale=0.03), rb(4 * D, D, scale=0.03)
 b3, b4, b1 = torch.randn(3 * D, device=dev), torch.randn(4 * D, device=dev), torch.randn(D, device=dev)
 calls = [
-    ("qkv", lambda t: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3, tile=t), 2.0 * M * D * 3 * D, (0, 1024, 24, 25, 30)),
-    ("fc1+gelu", lambda t: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4, tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 25, 30)),
-    ("dgrad_fc2", lambda t: ops.gemm_nt(x1, w2_t, ops.EPI_DMUL, aux=x4, colsum=torch.zeros(4 * D, device=dev), tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 26, 27)),
-    ("dgrad_fc1", lambda t: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 25, 30)),
-    ("dgrad_qkv", lambda t: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 3 * D, (0, 1024, 24, 25, 30)),
+    ("qkv", lambda t: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3, tile=t), 2.0 * M * D * 3 * D, (0, 1024, 24, 25, 30, 2048)),
+    ("fc1+gelu", lambda t: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4, tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 25, 30, 2048)),
+    ("dgrad_fc2", lambda t: ops.gemm_nt(x1, w2_t, ops.EPI_DMUL, aux=x4, colsum=torch.zeros(4 * D, device=dev), tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 2048)),
+    ("dgrad_fc1", lambda t: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 25, 30, 2048)),
+    ("dgrad_qkv", lambda t: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 3 * D, (0, 1024, 24, 25, 30, 2048)),
 ]
-names = {0: "auto", 512: "one-wg-per-tile", 1024: "persistent-no-seam", 24: "seam256", 25: "seam320", 26: "seam256 B-late", 27: "seam256 A+B-late", 28: "seam320 B-late", 29: "seam320 A+B-late"}
+names = {0: "auto", 512: "one-wg-per-tile", 1024: "persistent-no-seam", 24: "seam256", 25: "seam320", 30: "seam256+table", 2048: "loader-waves"}
 only = os.environ.get("SHAPES")
 for name, fn, fl, tiles in calls:
     if only and name not in only.split(","): continue

@@ -1,11 +1,11 @@
 """Weight-gradient (TN) GEMM variants on the three ViT-B shapes: interleaved rounds in one process, random data, medians.
-usage: bench_tn.py [name=dbgbits ...]   (bits 26-28 select the kernel, see csrc/capi.hip)"""
+usage: bench_tn.py [name=dbgbits ...]   (bit 23 = the loader-wave form, bits 16-17 its timing-only ablations: csrc/gemm_tn.hip)"""
 import os, sys, statistics, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops, lib
 lib.use_experimental(); L = lib.load(); L.vitamd_set_debug.argtypes = [ctypes.c_int]
-cfgs = {"pp_d4": 0, "loader_waves": 0x800000, "ld_no_mfma(!)": 0x800000 | 1 << 16, "ld_no_lds_reads(!)": 0x800000 | 2 << 16, "ld_neither(!)": 0x800000 | 3 << 16} if os.environ.get("TN_BENCH_SHORT") == "1" else {"pp_d4": 0, "pp16": 4 << 26, "pp_d6": 7 << 26, "r1_vgpr_staged": 6 << 26, "loader_waves": 0x800000}
+cfgs = {"pp_d4": 0, "loader_waves": 0x800000, "ld_no_mfma(!)": 0x800000 | 1 << 16, "ld_no_lds_reads(!)": 0x800000 | 2 << 16, "ld_neither(!)": 0x800000 | 3 << 16} 
 for a in sys.argv[1:]:
     k, v = a.split("="); cfgs[k] = int(v, 0)
 dev = torch.device("cuda")

@@ -462,10 +462,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_small_kernel(const AttnArgs a
   PROBE_END(0)
 }
 
-#ifdef VITAMD_EXPERIMENTAL
-#include "experimental/attention_fwd_persistent.inc"
-#endif
-
 // ------------------------------------------------------------------------------------------ forward, 129 <= N <= 256, EIGHT waves (round 3)
 // attn_fwd_small_kernel gives each of its 4 waves up to two 32-row query blocks, needs 229 registers for the register-resident score row and is
 // bound by memory round trips at 2 workgroups x 4 waves per CU (DESIGN.md sections 4.2, 4.4).  Here a workgroup has EIGHT waves - one query block
@@ -982,7 +978,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pipe_kernel(const AttnArg
 }
 
 #ifdef VITAMD_EXPERIMENTAL
-#include "experimental/attention_fused.inc"
 #include "experimental/attention_split.inc"
 #endif
 
@@ -1327,17 +1322,6 @@ static int attention_fwd_impl(const void* qkv, void* o, float* lse2, const float
     }
     return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
   }
-#ifdef VITAMD_EXPERIMENTAL
-  if (nkt >= 4 && nkt <= 8 && !resid_in && !drop && (VITAMD_GDBG & 0x2000)) {     // persistent form (dbg bit 13 of experimental builds: the per-head kernel)
-    const int lds = 4 * npad * 128 + 8 * 4096;
-    const int grid = B * H < 256 ? B * H : 256;
-    int e = VITAMD_OK;
-#define FWD_PERS(K) case K: e = set_lds(attn_fwd_pers_kernel<K, false>, lds); if (!e) hipLaunchKernelGGL((attn_fwd_pers_kernel<K, false>), dim3(grid), dim3(512), lds, stream, a); break;
-    switch (nkt) { FWD_PERS(4) FWD_PERS(5) FWD_PERS(6) FWD_PERS(7) FWD_PERS(8) }
-#undef FWD_PERS
-    if (e) return e;
-  } else
-#endif
   if (nkt >= 5 && nkt <= 8 && !drop && !causal && !(VITAMD_GDBG & 0x8000)) {      // eight waves, one query block each (dbg bit 15 of experimental builds: off)
     const int lds = 2 * npad * 128 + 8 * 2048;
     int e = VITAMD_OK;
@@ -1393,20 +1377,6 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
     return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
   }
   const int npad = (N + 31) / 32 * 32;
-#ifdef VITAMD_EXPERIMENTAL
-  if (npad <= 32 * FUSED_MAX_NT && (g_vitamd_debug & 0x200)) {      // dbg bit 9: the one-pass fused kernel (measured: 290 us against 265 us for the two kernels at B=256, N=197, H=12 - its load/store phase (147 us) and its lock-stepped compute (142 us) do not overlap with one workgroup per CU)
-    const int ldsf = 3 * npad * 128 + 2 * npad * 4 + 8 * 2048 + 8 * 4096;
-    a.causal = (causal ? 1 : 0) | ((g_vitamd_debug >> 9) & 14);
-    if (a.drop_thresh) {
-      if (int e = set_lds(attn_bwd_fused_kernel<true>, ldsf)) return e;
-      hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(B * H), dim3(512), ldsf, stream, a);
-    } else {
-      if (int e = set_lds(attn_bwd_fused_kernel<false>, ldsf)) return e;
-      hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(B * H), dim3(512), ldsf, stream, a);
-    }
-    return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
-  }
-#endif
   const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
   const dim3 grid(B * H), block(256);
   const int nkt = npad / 32;

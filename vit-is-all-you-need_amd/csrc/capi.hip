@@ -10,13 +10,10 @@ extern "C" int vitamd_init(int device, void* stream) { return vitamd_init_impl(d
 
 #ifdef VITAMD_EXPERIMENTAL
 int g_vitamd_debug = 0;
-// Diagnostics knob of the EXPERIMENTAL library only (libvitamd_exp.so: tools/ab_*.py, tools/ablate_*.py); process-global, not in the
-// public header, absent from the production library.  Bits marked (!) make results wrong (timing only).
-//   NT GEMM : 5 no persistent launches (one workgroup per tile everywhere)   2 every tile stores to the same rows(!)   3 plain (temporal) output stores   4 tail split for every GEMM   7 no fc2-forward
-//             tail split   16 no output stores(!)   18 every tile loads L2-resident panels(!)   19 no 320-row tiles   29 pipe kernel staged
-//             through VGPRs   30 the round-1 pipe kernel instead of the ping-pong kernel
-//   TN GEMM : 6 round-1 16x16x32 form   25 256x384-tile kernel   26-28: 1-3 round-1 timing ablations(!), 5 round-1 LDS-DMA, 6 round-1 VGPR-staged, 7 ping-pong D = 6
-//   attention: 9 one-pass fused backward   10-12 its timing probes(!)
+// Diagnostics knobs of the EXPERIMENTAL library only (libvitamd_exp.so: tools/ab_*.py, tools/ablate_*.py, tools/bench_ld.py); process-global, not in the
+// public header, absent from the production library.  Bits marked (!) make results wrong (timing only).  Each kernel file documents its own bits
+// where it reads them (VITAMD_DBG / g_vitamd_debug / g_vitamd_debug2); the measured alternative KERNELS of rounds 1-3 that these words used to select
+// were deleted in round 4 (their numbers live in DESIGN.md and under profiles/r02, profiles/r03).
 extern "C" int vitamd_set_debug(int bits) { g_vitamd_debug = bits; return 0; }
 int g_vitamd_debug2 = 0;     // second word (experiments of round 4 on: the first one is full): bits 0-3 = which launch classes take the loader-wave NT form (gemm_nt.hip::ld_auto)
 extern "C" int vitamd_set_debug2(int bits) { g_vitamd_debug2 = bits; return 0; }
@@ -31,7 +28,7 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
   if (epi == 7) epi = EPI_DGELU;
   GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, VITAMD_GDBG, 0u, 1.0f, 0u, 0u, 0, dg};
 #ifdef VITAMD_EXPERIMENTAL
-  if (!(tile >= 0 && tile <= 30) && tile != 128 && tile != 256 && tile != 257 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048 && tile != 2049) return VITAMD_ERR_ARG;
+  if (tile != 0 && tile != 24 && tile != 25 && tile != 30 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048 && tile != 2049) return VITAMD_ERR_ARG;
 #else
   if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) return VITAMD_ERR_ARG;
 #endif

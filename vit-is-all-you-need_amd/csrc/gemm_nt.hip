@@ -419,22 +419,14 @@ int vitamd_init_impl(int device, hipStream_t stream) {
 namespace {
 
 #ifdef VITAMD_EXPERIMENTAL
-#include "experimental/gemm_nt_variants.inc"
-// tile codes 24 / 25 (experimental builds): the seam kernel (gemm_nt_seam.h) on 256- / 320-row tiles whatever the automatic rule says
+// tile codes 24 / 25 / 30 (experimental builds): the seam kernel (gemm_nt_seam.h) on 256- / 320-row tiles whatever the automatic rule says
 template <int EPI>
 int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
   if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU) {
     if (!seam_ok(p)) return VITAMD_ERR_SHAPE;
-    if (tile == 24) return launch_seam<EPI, 8>(p, stream, device_cus());
-    if constexpr (EPI == EPI_GELU) {
-      if (tile == 30) return launch_seam<EPI, 8, 0, true>(p, stream, device_cus());          // 256-row tiles with the GELU table
-    }
-    if (tile == 26) return launch_seam<EPI, 8, 1>(p, stream, device_cus());      // request placement experiments: B request in the matrix section
-    if (tile == 27) return launch_seam<EPI, 8, 2>(p, stream, device_cus());      // A and B requests in the matrix section
-    if constexpr (EPI != EPI_DGELU) {
-      if (tile == 28) return launch_seam<EPI, 10, 1>(p, stream, device_cus());
-      if (tile == 29) return launch_seam<EPI, 10, 2>(p, stream, device_cus());
-      return launch_seam<EPI, 10>(p, stream, device_cus());
+    if (tile == 24 || tile == 30) return launch_seam<EPI, 8, EPI == EPI_GELU>(p, stream, device_cus());      // (GELU: always the table form)
+    if constexpr (EPI == EPI_BIAS_BF16) {
+      if (tile == 25) return launch_seam<EPI, 10>(p, stream, device_cus());
     }
   }
   return VITAMD_ERR_ARG;
@@ -510,22 +502,13 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   constexpr bool seam_epi = EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU;
   constexpr bool tall_epi = seam_epi || EPI == EPI_RESID_F32;
 #ifdef VITAMD_EXPERIMENTAL
-  {   // experimental builds: further tile codes select the measured alternatives (experimental/gemm_nt_variants.inc)
+  {   // experimental builds: further tile codes force a kernel form whatever the automatic rule says
     int tile = p.tile;
     if (tile >= 24 && tile <= 30) return dispatch_seam_explicit<EPI>(p, stream, tile);
     if (tile == 2049) {                     // the loader-wave form with its first request schedule (burst in phase 0)
       if constexpr (seam_epi) return ld_ok(p) ? launch_ld<EPI, EPI == EPI_GELU, 0>(p, stream, device_cus()) : VITAMD_ERR_SHAPE;
       return VITAMD_ERR_SHAPE;
     }
-    if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) {
-      const int r = dispatch_variant<EPI>(p, stream, tile == 7 ? 256 : tile, tile == 2 && prefer_tall(p));
-      if (r != -1) return r;
-      if (tile != 7 && tile != 8) return VITAMD_ERR_ARG;
-      GemmNtArgs q = p;
-      q.tile = tile == 7 ? 256 : 320;
-      return dispatch_tile<EPI>(q, stream);
-    }
-    if (tile == 0 && (VITAMD_DBG(p) & 0x40000000)) return dispatch_variant<EPI>(p, stream, 2, prefer_tall(p));   // dbg bit 30: the round-1 pipe kernel
   }
 #endif
   const NtPlan pl = plan_single(p);
@@ -536,7 +519,7 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
       break;
     case NT_FORM_SEAM:
       if constexpr (EPI == EPI_BIAS_BF16) { if (pl.rows == 320) return launch_seam<EPI, 10>(p, stream, device_cus()); }
-      if constexpr (seam_epi) return launch_seam<EPI, 8, 0, EPI == EPI_GELU>(p, stream, device_cus());
+      if constexpr (seam_epi) return launch_seam<EPI, 8, EPI == EPI_GELU>(p, stream, device_cus());
       break;
     case NT_FORM_PP_PERSISTENT:
       if constexpr (tall_epi) { if (pl.rows == 320) return launch_pp<EPI, 10, 4, 6, true>(p, stream); }

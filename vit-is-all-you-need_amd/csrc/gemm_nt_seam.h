@@ -22,10 +22,10 @@
 
 namespace {
 
-// RQ: where a phase's requests are issued.  0 = both in the read section, ahead of the phase's counted wait (round-2 placement);
-// 1 = the A request there, the B request (when the phase has one) in the MATRIX section behind its 8th MFMA; 2 = A behind the 4th, B behind the 12th MFMA.
-// A request issued in the matrix section comes after its phase's wait in program order: the counts below follow that order.
-template <int MT, int LA, int RQ = 0>
+// (A request-placement experiment of round 3 - the B request, or both requests, issued from inside the matrix section - measured slower everywhere
+// and was removed in round 4: profiles/r03/request_placement_experiment.log.)  Both requests of a phase are issued in its read section, ahead of the
+// phase's counted wait.
+template <int MT, int LA>
 struct SeamSchedule {
   static constexpr int NP = MT / 2;
   static_assert(MT % 2 == 0 && NP >= 4 && NP <= 5, "tile height");
@@ -52,32 +52,25 @@ struct SeamSchedule {
     int allowed = 0;
     for (int d = 0; d < 4 * NP; ++d) {
       const int f = ((ph - d) % NP + NP) % NP;
-      // reverse program order inside phase ph - d: [late B] [late A] | its wait | [early B] [early A]; the late ones of the CURRENT phase (d = 0)
-      // have not been issued yet when its wait executes
-      for (int late = 1; late >= 0; --late) {
-        if (late && d == 0) continue;
-        if ((RQ >= 1) == (late == 1))
-          for (int q = 3; q >= 0; --q)
-            if (b_here(f, q)) {
-              if (d + 1 >= blead(q)) return allowed + (d > ph ? E : 0);
-              ++allowed;
-            }
-        if ((RQ >= 2) == (late == 1)) {
-          if (d + 1 >= LA) return allowed + (d > ph ? E : 0);
+      // reverse program order inside phase ph - d: its wait | [B requests] [A request]
+      for (int q = 3; q >= 0; --q)
+        if (b_here(f, q)) {
+          if (d + 1 >= blead(q)) return allowed + (d > ph ? E : 0);
           ++allowed;
         }
-      }
+      if (d + 1 >= LA) return allowed + (d > ph ? E : 0);
+      ++allowed;
     }
     return allowed;
   }
 };
 
-template <int EPI, int MT, int RQ = 0, bool TAB = false>
+template <int EPI, int MT, bool TAB = false>
 __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
   static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU, "epilogues without (or with up-front) auxiliary loads");
   static_assert(!TAB || (EPI == EPI_GELU && MT == 8), "the GELU table needs the 16 KiB that only the 256-row ring leaves");
   constexpr int LA = 4;
-  using S = SeamSchedule<MT, LA, RQ>;
+  using S = SeamSchedule<MT, LA>;
   constexpr int NP = S::NP;
   constexpr int BM = 32 * MT, BN = 256, WN = 4, NT = 4;
   constexpr int PART = 8192, ASLOT = NP * PART, BSLOT = 32768, BBASE = 2 * ASLOT, OPS = BBASE + 2 * BSLOT;
@@ -204,12 +197,10 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
           af[i][0] = *(const bf16x8*)(pa0 + ph * PART + i * 2048);
           af[i][1] = *(const bf16x8*)(pa1 + ph * PART + i * 2048);
         }
-        if constexpr (RQ < 2) request_a(kt + S::a_tile(ph), S::a_part(ph));
-        if constexpr (RQ < 1) {
+        request_a(kt + S::a_tile(ph), S::a_part(ph));
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (S::b_here(ph, q)) request_b(kt + S::b_tile(ph, q), q);
-        }
+        for (int q = 0; q < 4; ++q)
+          if (S::b_here(ph, q)) request_b(kt + S::b_tile(ph, q), q);
         if (S::wait(ph, E) != S::wait(ph) && lenient) VITAMD_WAIT_VM(S::wait(ph, E));
         else VITAMD_WAIT_VM(S::wait(ph));
         __builtin_amdgcn_sched_barrier(0);
@@ -223,22 +214,6 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-              if constexpr (RQ >= 1) {       // requests placed in the matrix section: behind the 4th (A, RQ 2) and the 8th / 12th (B) MFMA
-                constexpr int A_AT = 4, B_AT = RQ == 1 ? 8 : 12;
-                const int n = ks * 8 + i * 4 + j;
-                if (RQ == 2 && n == A_AT) {
-                  __builtin_amdgcn_sched_barrier(0);
-                  request_a(kt + S::a_tile(ph), S::a_part(ph));
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-                if (n == B_AT) {
-                  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                  for (int q = 0; q < 4; ++q)
-                    if (S::b_here(ph, q)) request_b(kt + S::b_tile(ph, q), q);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-              }
               acc[2 * ph + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j][ks], af[i][ks], acc[2 * ph + i][j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
@@ -414,9 +389,9 @@ __global__ __launch_bounds__(512) void gemm_nt_seam_kernel(const GemmNtArgs p) {
 #undef VITAMD_WAIT_VM
 }
 
-template <int EPI, int MT, int RQ = 0, bool TAB = false>
+template <int EPI, int MT, bool TAB = false>
 int launch_seam(const GemmNtArgs& p, hipStream_t stream, int cus) {
-  auto kern = gemm_nt_seam_kernel<EPI, MT, RQ, TAB>;
+  auto kern = gemm_nt_seam_kernel<EPI, MT, TAB>;
   if (TAB && !p.gelu_tab) return VITAMD_ERR_ARG;
   if (int e = set_lds(kern, 160 * 1024)) return e;
   const int tiles = ((p.M + 32 * MT - 1) / (32 * MT)) * ((p.N + 255) / 256);

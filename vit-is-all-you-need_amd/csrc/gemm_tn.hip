@@ -333,10 +333,6 @@ __global__ __launch_bounds__(768) void gemm_tn_ld_kernel(const GemmTnArgs a, int
   }
 }
 
-#ifdef VITAMD_EXPERIMENTAL
-#include "experimental/gemm_tn_variants.inc"
-#endif
-
 // out[p][q] (+)= sum_s ws[s][tile][p_local][q_local]; RPT float4 per thread
 constexpr int RPT = 1;      // 4 is faster back to back (9.2 vs ~12 us) but slower inside the step (13.9 vs 12.0 us)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int P, int Q, int ldo,
@@ -387,18 +383,7 @@ static int auto_splits(int R, int P, int Q, int requested) {
 
 extern "C" long vitamd_gemm_tn_ws_bytes(int R, int P, int Q, int splits) {
   if (R <= 0 || P <= 0 || Q <= 0) return 0;
-#ifdef VITAMD_EXPERIMENTAL
-  if (vitamd_gemm_tn_wide_ok(R, P, Q, splits)) return (long)vitamd_gemm_tn_wide_splits(R, P, Q) * P * Q * (long)sizeof(float);
-#endif
   const long ntile = (long)((P + BP - 1) / BP) * ((Q + BQ - 1) / BQ);
-#ifdef VITAMD_EXPERIMENTAL
-  if (g_vitamd_debug & 0x20000000) {                 // room for the 384-row tiles split factor (bit 29)
-    const int nt384 = ((P + 383) / 384) * ((Q + BQ - 1) / BQ);
-    int s384 = 252 / nt384; if (s384 < 1) s384 = 1;
-    const int s = auto_splits(R, P, Q, splits);
-    return (long)(s384 > s ? s384 : s) * ntile * BP * BQ * (long)sizeof(float);
-  }
-#endif
   return (long)auto_splits(R, P, Q, splits) * ntile * BP * BQ * (long)sizeof(float);
 }
 
@@ -406,11 +391,6 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   if (a.R <= 0 || a.P <= 0 || a.Q <= 0 || a.ldl % 8 || a.ldr % 8 || a.ldl < a.P || a.ldr < a.Q || a.ldo < a.Q) return VITAMD_ERR_SHAPE;
   if ((size_t)(a.R + BR) * a.ldl * 2 >= 0x80000000ull || (size_t)(a.R + BR) * a.ldr * 2 >= 0x80000000ull) return VITAMD_ERR_SHAPE;
   if (!a.L || !a.Rm || !a.out) return VITAMD_ERR_ARG;
-#ifdef VITAMD_EXPERIMENTAL
-  if (a.ws && a.ldl == a.P && a.ldr == a.Q && vitamd_gemm_tn_wide_ok(a.R, a.P, a.Q, a.splits) &&
-      a.ws_bytes >= (size_t)vitamd_gemm_tn_wide_splits(a.R, a.P, a.Q) * a.P * a.Q * sizeof(float))
-    return vitamd_gemm_tn_wide_launch(a, stream);
-#endif
   const int tiles_p = (a.P + BP - 1) / BP, tiles_q = (a.Q + BQ - 1) / BQ;
   const int ntile = tiles_p * tiles_q;
   const int splits = auto_splits(a.R, a.P, a.Q, a.splits);
@@ -418,28 +398,6 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
   const bool use_ws = a.ws != nullptr && a.ws_bytes >= (size_t)splits * ntile * BP * BQ * sizeof(float);
   if (!use_ws && !a.accumulate) return VITAMD_ERR_ARG;      // overwrite mode needs the workspace: the atomic form can only add to `out`
   const dim3 grid(ntile * splits), block(NW * 64);
-#ifdef VITAMD_EXPERIMENTAL
-  {   // A/B knobs: bit 6 = 16x16x32 round-1 form; bits 26-28: 1-3 timing-only ablations, 4 = ping-pong on 16x16x32, 5 = round-1 LDS-DMA, 6 = round-1 VGPR-staged, 7 = ping-pong D = 6
-    const int sel = (g_vitamd_debug >> 26) & 7;
-    if (use_ws && (g_vitamd_debug & 0x80000000)) {   // bit 31: co-residency experiment: a 5-slot ring (80 KiB) leaves room for ONE attention-backward workgroup (74 KiB, 4 x 128 registers) on the CU
-      if (int e = set_lds(gemm_tn_pp_kernel<true, 5, 3>, 5 * QSLOT)) return e;
-      hipLaunchKernelGGL((gemm_tn_pp_kernel<true, 5, 3>), grid, block, 5 * QSLOT, stream, a, tiles_p, tiles_q, splits);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits, a.accumulate);
-      return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
-    }
-    if (use_ws && ((g_vitamd_debug & 64) || sel)) {
-      if (g_vitamd_debug & 64) { if (int e = set_lds(gemm_tn16_kernel<true>, lds)) return e; hipLaunchKernelGGL(gemm_tn16_kernel<true>, grid, block, lds, stream, a, tiles_p, tiles_q, splits); }
-      else {
-        auto kern = sel == 1 ? gemm_tn_kernel<true, 1> : sel == 2 ? gemm_tn_kernel<true, 2> : sel == 3 ? gemm_tn_kernel<true, 3>
-                  : sel == 5 ? gemm_tn_kernel<true, 0> : sel == 6 ? gemm_tn_kernel<true, 4> : sel == 4 ? gemm_tn_pp16_kernel<true> : gemm_tn_pp_kernel<true, 8, 6>;
-        if (int e = set_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, a, tiles_p, tiles_q, splits);
-      }
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, splits, a.accumulate);
-      return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
-    }
-  }
-#endif
   if (use_ws) {
     bool loader = a.form == 1;
 #ifdef VITAMD_EXPERIMENTAL
@@ -449,27 +407,11 @@ int vitamd_gemm_tn_impl(const GemmTnArgs& a, hipStream_t stream) {
 #endif
     if (loader) {
 #ifdef VITAMD_EXPERIMENTAL
-      if (g_vitamd_debug & 0x20000000) {             // bit 29: 384 x 256 tiles on twelve compute waves (gemm_tn_x12_kernel); needs the workspace of vitamd_gemm_tn_ws_bytes under the same bit
-        const int tp384 = (a.P + 383) / 384, nt384 = tp384 * tiles_q;
-        int s384 = 252 / nt384; if (s384 < 1) s384 = 1;
-        const int nsteps = (a.R + BR - 1) / BR; if (s384 > nsteps) s384 = nsteps;
-        if (a.ws_bytes < (size_t)s384 * ntile * BP * BQ * sizeof(float)) return VITAMD_ERR_ARG;
-        if (int e = set_lds(gemm_tn_x12_kernel<8, 4>, 8 * 20480)) return e;
-        hipLaunchKernelGGL((gemm_tn_x12_kernel<8, 4>), dim3(nt384 * s384), dim3(768), 8 * 20480, stream, a, tp384, tiles_q, s384, tiles_p);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(BP * BQ / 4 / 256 / RPT, ntile), dim3(256), 0, stream, a.ws, a.out, a.P, a.Q, a.ldo, tiles_q, ntile, s384, a.accumulate);
-        return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
-      }
-      const int dv = (g_vitamd_debug >> 16) & 7;     // bits 16-18: ring / prefetch-distance variants of the loader form (A/B)
-      if (dv >= 5) {
-        auto kern = dv == 5 ? gemm_tn_lda_kernel<8> : dv == 6 ? gemm_tn_ldv_kernel<8, 4> : gemm_tn_ldv_kernel<8, 6>;
+      const int dv = (g_vitamd_debug >> 16) & 3;     // bits 16-17: timing-only ablations of the loader form (1 no MFMAs, 2 no transposed reads, 3 neither; results garbage)
+      if (dv) {
+        auto kern = dv == 1 ? gemm_tn_ld_kernel<8, 4, 1> : dv == 2 ? gemm_tn_ld_kernel<8, 4, 2> : gemm_tn_ld_kernel<8, 4, 3>;
         if (int e = set_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, grid, dim3(768), lds, stream, a, tiles_p, tiles_q, splits);
-      } else if (dv) {
-        // 1-3: timing-only ablations of the loader form (no MFMAs / no transposed reads / neither); 4: ten-slot ring, 8 quarters ahead
-        auto kern = dv == 1 ? gemm_tn_ld_kernel<8, 4, 1> : dv == 2 ? gemm_tn_ld_kernel<8, 4, 2> : dv == 3 ? gemm_tn_ld_kernel<8, 4, 3> : gemm_tn_ld_kernel<10, 8>;
-        const int l2 = (dv == 4 ? 10 : 8) * QSLOT;
-        if (int e = set_lds(kern, l2)) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(768), l2, stream, a, tiles_p, tiles_q, splits);
       } else
 #endif
       {

@@ -52,7 +52,3 @@ int vitamd_gemm_nt_impl(const GemmNtArgs& p, hipStream_t stream);
 int vitamd_gemm_nt_plan_impl(const GemmNtArgs& p);
 int vitamd_init_impl(int device, hipStream_t stream);
 int vitamd_gemm_tn_impl(const GemmTnArgs& p, hipStream_t stream);
-// experimental builds only: 256x384-tile weight-gradient kernel (experimental/gemm_tn_wide.hip)
-bool vitamd_gemm_tn_wide_ok(int R, int P, int Q, int requested_splits);
-int vitamd_gemm_tn_wide_splits(int R, int P, int Q);
-int vitamd_gemm_tn_wide_launch(const GemmTnArgs& a, hipStream_t stream);
