@@ -469,6 +469,34 @@ def test_vq_nearest_wide_codes(hip):
         assert len(bad) <= max(1, M // 100)
 
 
+def test_vq_nearest_narrow_codes_cut_over_the_codebook(hip):
+    """d <= 64 with more than 256 codes (TiTok / ViT-VQGAN: 2 048 x 12): (row blocks) x (code chunks) workgroups folded with a 64-bit atomicMin of
+    (distance bits, index).  Integer-valued data make every distance exact, so the result must equal the exact first-minimum argmin - duplicates of
+    the winning code are planted in EARLIER and LATER chunks - and a second call must give the same bits; random data against float64 with a
+    near-tie allowance; K <= 256 still takes the single-pass kernel."""
+    from vitamd import ops
+    g = torch.Generator().manual_seed(12)
+    for (M, K, d) in ((8192, 2048, 12), (777, 1000, 16), (300, 2048, 33), (50, 256, 12)):
+        x = torch.randint(-4, 5, (M, d), generator=g).float()
+        e = torch.randint(-4, 5, (K, d), generator=g).float()
+        e[K - 1] = e[5]; e[K // 2] = e[5]; x[0] = e[5]; x[1] = e[K // 2]      # exact duplicates across chunks: the lowest index must win
+        d2 = (x.unsqueeze(1) - e.unsqueeze(0)).pow(2).sum(-1)                # exact in fp32 (integers < 2^24)
+        ref = d2.argmin(dim=1)                                               # torch returns the first minimum
+        first = (d2 == d2.min(dim=1, keepdim=True).values).float().argmax(dim=1)
+        assert torch.equal(ref, first)
+        i1 = ops.vq_nearest(x.cuda(), e.cuda()).cpu()
+        i2 = ops.vq_nearest(x.cuda(), e.cuda()).cpu()
+        assert torch.equal(i1, ref) and torch.equal(i1, i2) and int(i1[0]) <= 5 and int(i1[1]) <= 5, (M, K, d)
+    x = W.normal(10, "xn", (4096, 12)); e = W.normal(10, "en", (2048, 12))
+    idx = ops.vq_nearest(x.cuda(), e.cuda()).cpu()
+    d2 = (x.double().unsqueeze(1) - e.double().unsqueeze(0)).pow(2).sum(-1)
+    ref = d2.argmin(dim=1)
+    bad = (idx != ref).nonzero().flatten().tolist()
+    for m in bad:
+        assert abs(float(d2[m, idx[m]] - d2[m, ref[m]])) < 1e-5 * float(d2[m, ref[m]])
+    assert len(bad) <= 4
+
+
 def test_blocks_drop_rates_are_identity_in_eval(hip):
     """Reference semantics: nn.Dropout / DropPath do nothing in eval mode (blocks.py:124-139).  A block built WITH drop rates
     must reproduce the reference's (drop-free) golden output in eval mode; training with the rates on is covered by

@@ -1380,7 +1380,7 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
   const int lds1 = 2 * npad * 128 + 4 * 4096, lds2 = 2 * npad * 128 + 2 * npad * 4 + 4 * 4096;
   const dim3 grid(B * H), block(256);
   const int nkt = npad / 32;
-  if (!a.drop_thresh && !a.causal && nkt >= 2 && nkt <= 8 && !(VITAMD_GDBG & 0x20000)) {     // the ViT shapes: pipelined forms (dbg bit 17 of experimental builds: the plain loops)
+  if (!a.drop_thresh && !a.causal && nkt >= 2 && nkt <= 7 && !(VITAMD_GDBG & 0x20000)) {      // (round 4, tools/ab_attn_bwd_pipe.py: with 8 / 9 key tiles - 256 tokens: ViT-VQGAN, 288: TiTok - the fully unrolled kernels LOSE to the plain loops, 604 against 402 us at B 256, N 256, H 12 and 597 against 440 at N 288; 2-7 tiles: equal to 13 % faster)     // the ViT shapes: pipelined forms (dbg bit 17 of experimental builds: the plain loops)
     int e = VITAMD_OK;
 #ifdef VITAMD_EXPERIMENTAL
     if (nkt <= 7 && (g_vitamd_debug2 & 16)) {            // one staging of the head, split roles (attn_bwd_split_kernel)
@@ -1393,11 +1393,11 @@ extern "C" int vitamd_attention_bwd(const void* qkv, const void* o, const float*
     }
 #endif
 #define DQ_PIPE(K) case K: e = set_lds(attn_bwd_dq_pipe_kernel<K>, lds1); if (!e) hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel<K>, grid, block, lds1, stream, a); break;
-    switch (nkt) { DQ_PIPE(2) DQ_PIPE(3) DQ_PIPE(4) DQ_PIPE(5) DQ_PIPE(6) DQ_PIPE(7) DQ_PIPE(8) }
+    switch (nkt) { DQ_PIPE(2) DQ_PIPE(3) DQ_PIPE(4) DQ_PIPE(5) DQ_PIPE(6) DQ_PIPE(7) }
 #undef DQ_PIPE
     if (e) return e;
 #define DKV_PIPE(K) case K: e = set_lds(attn_bwd_dkv_pipe_kernel<K>, lds2); if (!e) hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<K>, grid, block, lds2, stream, a); break;
-    switch (nkt) { DKV_PIPE(2) DKV_PIPE(3) DKV_PIPE(4) DKV_PIPE(5) DKV_PIPE(6) DKV_PIPE(7) DKV_PIPE(8) }
+    switch (nkt) { DKV_PIPE(2) DKV_PIPE(3) DKV_PIPE(4) DKV_PIPE(5) DKV_PIPE(6) DKV_PIPE(7) }
 #undef DKV_PIPE
     if (e) return e;
     return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;

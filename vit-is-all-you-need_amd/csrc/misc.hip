@@ -294,6 +294,39 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
   if (m < M) idx[m] = besti;
 }
 
+// The same search cut over the codebook too (round 4): grid = (row blocks) x (256-code chunks); every thread scans ONE chunk for its row with the
+// arithmetic of vq_nearest_kernel and folds (distance bits << 32 | index) into its row's slot of the index buffer with a 64-bit atomicMin - a
+// non-negative float orders like its bit pattern, so the minimum of the packed words is the smallest distance and, among equal distances, the
+// smallest index: exactly the first-minimum tie-break of the sequential scan, whatever order the chunks arrive in.  vq_unpack_kernel then keeps the low
+// half.  TiTok-S (8 192 tokens x 2 048 codes x 12) ran on 32 workgroups for 1.08 ms with one thread per row; 256 workgroups now.
+template <int DMAX>
+__global__ __launch_bounds__(256) void vq_nearest_chunk_kernel(const float* __restrict__ x, const float* __restrict__ e,
+                                                               unsigned long long* __restrict__ packed, int M, int K, int d) {
+  __shared__ float ce[256 * DMAX];
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * 256, nk = min(256, K - k0);
+  float xr[DMAX];
+#pragma unroll
+  for (int c = 0; c < DMAX; ++c) xr[c] = (m < M && c < d) ? x[(size_t)m * d + c] : 0.f;
+  for (int i = threadIdx.x; i < nk * d; i += 256) ce[(i / d) * DMAX + (i % d)] = e[(size_t)k0 * d + i];
+  __syncthreads();
+  float best = 3.0e38f;
+  int besti = k0;
+  for (int k = 0; k < nk; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) {
+      if (c < d) { const float t = xr[c] - ce[k * DMAX + c]; s += t * t; }
+    }
+    if (s < best) { best = s; besti = k0 + k; }
+  }
+  if (m < M) atomicMin(packed + m, ((unsigned long long)__builtin_bit_cast(unsigned, best) << 32) | (unsigned)besti);
+}
+__global__ __launch_bounds__(256) void vq_unpack_kernel(unsigned long long* __restrict__ packed, int M) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m < M) packed[m] &= 0xffffffffull;
+}
+
 // Wide codes (64 < d <= 1024, e.g. the reference blocks.VectorQuantizer default token_size 256, blocks.py:408):
 // a block owns 8 rows (staged in LDS); every thread walks the codes k = tid, tid+256, ... computing the 8
 // distances of its code in one pass over the code's floats (the codebook is a few MB and stays in L2), then
@@ -360,6 +393,14 @@ extern "C" int vitamd_vq_nearest(const float* x, const float* codebook, long lon
     return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
   }
   const int grid = (M + 255) / 256;
+  if (K > 256) {       // cut over the codebook as well: (row blocks) x (code chunks) workgroups + a 64-bit atomicMin per (row, chunk); see vq_nearest_chunk_kernel
+    if (hipMemsetAsync(idx, 0xff, (size_t)M * sizeof(long long), (hipStream_t)stream) != hipSuccess) return VITAMD_ERR_LAUNCH;
+    const dim3 g2(grid, (K + 255) / 256);
+    if (d <= 16) hipLaunchKernelGGL(vq_nearest_chunk_kernel<16>, g2, dim3(256), 0, (hipStream_t)stream, x, codebook, (unsigned long long*)idx, M, K, d);
+    else hipLaunchKernelGGL(vq_nearest_chunk_kernel<64>, g2, dim3(256), 0, (hipStream_t)stream, x, codebook, (unsigned long long*)idx, M, K, d);
+    hipLaunchKernelGGL(vq_unpack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)idx, M);
+    return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
+  }
   if (d <= 16) hipLaunchKernelGGL(vq_nearest_kernel<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, codebook, idx, M, K, d);
   else hipLaunchKernelGGL(vq_nearest_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, codebook, idx, M, K, d);
   return hipGetLastError() == hipSuccess ? VITAMD_OK : VITAMD_ERR_LAUNCH;
