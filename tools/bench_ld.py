@@ -27,7 +27,7 @@ calls = [
     ("dgrad_qkv", lambda t: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 3 * D),
 ]
 cfgs = {"auto": (0, 0), "loader": (2048, 0)}
-if EXP: cfgs.update({"ld_burst": (2049, 0), "ld_oob": (2048, 1), "ld_noreq": (2048, 2), "ld_Ares": (2048, 4), "ld_Bres": (2048, 8), "ld_ABres": (2048, 12), "ld_Acont": (2048, 16), "ld_ABcont": (2048, 48)})
+if EXP: cfgs.update({"ld10_320": (4096, 0), "ld_burst": (2049, 0), "ld_oob": (2048, 1), "ld_noreq": (2048, 2), "ld_Ares": (2048, 4), "ld_Bres": (2048, 8), "ld_ABres": (2048, 12), "ld_Acont": (2048, 16), "ld_ABcont": (2048, 48)})
 def setdbg(d):
     if EXP: _lib.load().vitamd_set_debug(d & 0xff); _lib.load().vitamd_set_debug2(d >> 8 << 8)
 tot = {k: 0.0 for k in cfgs}
@@ -37,7 +37,10 @@ for name, fn, fl in calls:
     for rnd in range(5):
         for k, (t, dbg) in cfgs.items():
             setdbg(dbg)
-            out = fn(t)
+            try:
+                out = fn(t)
+            except _lib.VitamdError:
+                setdbg(0); res[k].append(float("nan")); continue
             if rnd == 0 and dbg == 0:
                 torch.cuda.synchronize()
                 outs = out if isinstance(out, tuple) else (out,)

@@ -23,8 +23,9 @@ def rnd(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev, BF16)
 
 
-# explicit seam-kernel codes (24 = 256-row tiles, 25 = 320-row, 30 = 256-row with the GELU table) and the loader kernel's burst schedule (2049)
-for (M, N, K, tile) in [(512, 512, 128, 24), (256 * 40, 768, 768, 24), (320 * 30 + 64, 768, 768, 25), (512, 512, 128, 25), (256 * 40, 768, 256, 2049), (1000, 264, 128, 2049)]:
+# explicit seam-kernel codes (24 = 256-row tiles, 25 = 320-row, 30 = 256-row with the GELU table), the loader kernel's burst schedule (2049) and the
+# 320-row loader form on ten compute waves (4096)
+for (M, N, K, tile) in [(512, 512, 128, 24), (256 * 40, 768, 768, 24), (320 * 30 + 64, 768, 768, 25), (512, 512, 128, 25), (256 * 40, 768, 256, 2049), (1000, 264, 128, 2049), (320 * 30 + 7, 768, 256, 4096), (1000, 264, 128, 4096)]:
     a, b = ints((M, K), -1, 1, 5), ints((N, K), -1, 1, 6)
     out = ops.gemm_nt(a.to(dev, BF16), b.to(dev, BF16), ops.EPI_BIAS_BF16, tile=tile)
     if not torch.equal(out.float().cpu(), (a @ b.t()).to(BF16).float()):

@@ -3,13 +3,16 @@ bit for bit (same per-accumulator k order), every epilogue of the loader form, r
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
-from vitamd import ops
+from vitamd import ops, lib as _lib
+if "--exp" in sys.argv: _lib.use_experimental()      # also checks the 320-row form on ten compute waves (tile code 4096: experimental library only)
+EXP = "--exp" in sys.argv
 dev = torch.device("cuda")
 g = torch.Generator(device="cpu").manual_seed(7)
 def rb(*s, scale=1.0): return (torch.randn(*s, generator=g) * scale).to(dev, torch.bfloat16)
 bad = 0
 shapes = [(1024, 768, 256), (1000, 264, 128), (256 * 40, 2304, 768), (153600, 256, 128), (50432, 768, 3072), (50432, 2304, 768), (50000, 3072, 768)]
-if len(sys.argv) > 1: shapes = shapes[: int(sys.argv[1])]
+_a = [v for v in sys.argv[1:] if not v.startswith("--")]
+if _a: shapes = shapes[: int(_a[0])]
 for (M, N, K) in shapes:
     a, b = rb(M, K), rb(N, K, scale=0.05)
     bias = torch.randn(N, device=dev)
@@ -26,6 +29,13 @@ for (M, N, K) in shapes:
                 o = o if isinstance(o, tuple) else (o,)
                 outs[t] = [x.clone() for x in o] + ([cs] if epi == ops.EPI_DMUL else [])
             ok = True
+            if EXP and epi == ops.EPI_BIAS_BF16 and K % 128 == 0:             # the 320-row form (ten compute + two loader waves; tile code 4096): plain-bias epilogue only
+                y320 = ops.gemm_nt(a, b, epi, tile=4096, bias=bias)
+                torch.cuda.synchronize()
+                if not torch.equal(y320, outs[256][0]):
+                    d = (y320.float() - outs[256][0].float()); rows = torch.nonzero((d != 0).any(dim=1)).flatten()
+                    print(f"   ld10: {int((d != 0).sum())} elements differ, rows {rows[:6].tolist()}..{rows[-3:].tolist()} nan {int(torch.isnan(y320.float()).sum())}")
+                    ok = False
             for idx, (x, y) in enumerate(zip(outs[256], outs[2048])):
                 if x.dtype == torch.float32:      # column sums: atomics order differs
                     if not torch.allclose(x, y, rtol=1e-4, atol=1e-2): ok = False; print("   colsum diff", float((x - y).abs().max()))

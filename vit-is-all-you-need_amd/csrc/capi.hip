@@ -28,7 +28,7 @@ extern "C" int vitamd_gemm_nt_bf16(const void* A, const void* B, void* out, void
   if (epi == 7) epi = EPI_DGELU;
   GemmNtArgs p{A, B, out, out2, bias, aux, colsum, M, N, K, ldo, epi, n_patches, seq, extra, tile, VITAMD_GDBG, 0u, 1.0f, 0u, 0u, 0, dg};
 #ifdef VITAMD_EXPERIMENTAL
-  if (tile != 0 && tile != 24 && tile != 25 && tile != 30 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048 && tile != 2049) return VITAMD_ERR_ARG;
+  if (tile != 0 && tile != 24 && tile != 25 && tile != 30 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048 && tile != 2049 && tile != 4096) return VITAMD_ERR_ARG;
 #else
   if (tile != 0 && tile != 128 && tile != 256 && tile != 320 && tile != 512 && tile != 1024 && tile != 2048) return VITAMD_ERR_ARG;
 #endif

@@ -419,6 +419,7 @@ int vitamd_init_impl(int device, hipStream_t stream) {
 namespace {
 
 #ifdef VITAMD_EXPERIMENTAL
+#include "experimental/gemm_nt_ld10.inc"
 // tile codes 24 / 25 / 30 (experimental builds): the seam kernel (gemm_nt_seam.h) on 256- / 320-row tiles whatever the automatic rule says
 template <int EPI>
 int dispatch_seam_explicit(const GemmNtArgs& p, hipStream_t stream, int tile) {
@@ -505,6 +506,10 @@ int dispatch_tile(const GemmNtArgs& p, hipStream_t stream) {
   {   // experimental builds: further tile codes force a kernel form whatever the automatic rule says
     int tile = p.tile;
     if (tile >= 24 && tile <= 30) return dispatch_seam_explicit<EPI>(p, stream, tile);
+    if (tile == 4096) {                     // the 320-row loader form on ten compute + two loader waves (experimental/gemm_nt_ld10.inc)
+      if constexpr (EPI == EPI_BIAS_BF16) return ld10_ok(p) ? launch_ld10(p, stream, device_cus()) : VITAMD_ERR_SHAPE;
+      return VITAMD_ERR_SHAPE;
+    }
     if (tile == 2049) {                     // the loader-wave form with its first request schedule (burst in phase 0)
       if constexpr (seam_epi) return ld_ok(p) ? launch_ld<EPI, EPI == EPI_GELU, 0>(p, stream, device_cus()) : VITAMD_ERR_SHAPE;
       return VITAMD_ERR_SHAPE;
