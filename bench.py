@@ -93,7 +93,7 @@ def kernel_roofline(dev):
                 "launches_per_step": len(seq), "avg_launch_us": round(ms * 1e3 / len(seq), 1), "per_shape_tflops": detail,
                 "recorded_mfma_util": (prof.get("mfma_util") or {}).get(kernel), "recorded_traffic": (prof.get("traffic") or {}).get(kernel)}
 
-    nt = family(nt_calls, "gemm_nt")          # gemm_nt_pp_kernel and its seam form gemm_nt_seam_kernel
+    nt = family(nt_calls, "gemm_nt")          # gemm_nt_pp_kernel, gemm_nt_ld_kernel (and gemm_nt_seam_kernel for odd K-tile counts)
     tn = family(tn_calls, "gemm_tn")          # gemm_tn_pp_kernel (8 waves) and gemm_tn_ld_kernel (12 waves, loader waves)
     # (informational) the same weight-gradient GEMMs cut for the whole chip (252 workgroups) instead of the ~128 the step uses so that
     # they leave half the CUs to the main stream's kernels
@@ -104,7 +104,7 @@ def kernel_roofline(dev):
     # this same command committed under profiles/ (collected with --pmc in separate runs, as the guide prescribes), and say so: "static": true;
     # "stale": true when the kernel sources have changed since those passes were made (then `traffic` is null).
     rec_ok = prof.get("source") is not None and not prof.get("stale")
-    out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel + gemm_nt_seam_kernel (320x256x64 / 256x256x64 ping-pong tiles; the 72 large NT GEMM launches of one step, in layer order)",
+    out = {"bound": "mfma", "kernel": "gemm_nt_pp_kernel (320x256x64 ping-pong tiles: the N = 768 GEMMs) + gemm_nt_ld_kernel (256x256x64, 8 compute + 4 loader waves: QKV, fc1+GELU, dgrad-fc2); the 72 large NT GEMM launches of one step, in layer order",
            "instantiations": step_table,
            "achieved": nt["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": nt["frac"],
            "traffic": (nt["recorded_traffic"] or {}).get("bytes_per_launch") if rec_ok else None,
@@ -113,7 +113,8 @@ def kernel_roofline(dev):
            "per_shape_tflops": nt["per_shape_tflops"], "kernels": {"gemm_nt": nt, "gemm_tn": tn},
            # what these main loops are observed to get: ~17 B per clock per CU of operand fill (one 1-KiB LDS-DMA piece per ~60
            # cycles; the bare path does 52-58 from L2), where a 256x256 (320x256) tile needs 32 (28.8) B per clock at full MFMA rate
-           "feed_ceiling": {"bytes_per_clk_per_cu": 17, "frac_of_mfma_peak": {"256x256": 0.53, "320x256": 0.59}, "source": "DESIGN.md 4.6, profiles/r03/tn_loader_ring_variants.log"}}
+           "feed_ceiling": {"bytes_per_clk_per_cu": {"requests_from_compute_waves": 17, "four_loader_waves": 21.5}, "frac_of_mfma_peak": {"256x256": 0.53, "320x256": 0.59, "256x256_loader_waves": 0.67},
+                            "source": "DESIGN.md 4.6 / 4.7, profiles/r03/tn_loader_ring_variants.log, profiles/r04/nt_loader_vs_auto_ablations.log"}}
     return out
 
 
