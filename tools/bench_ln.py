@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "vit-is-all-you-need_amd"))
 from vitamd import ops, lib
 if len(sys.argv) > 1 and sys.argv[1] == "sweep": lib.use_experimental()
 dev = torch.device("cuda")
-M, D = 256 * 197, 768
+M, D = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256 * 197, 768)     # usage: bench_ln.py [sweep|-] [M D]
 g = torch.Generator(device="cpu").manual_seed(2)
 xf = torch.randn(M, D, generator=g).to(dev); add = torch.randn(M, D, generator=g).to(dev, torch.bfloat16)
 dy = torch.randn(M, D, generator=g).to(dev, torch.bfloat16); res = torch.randn(M, D, generator=g).to(dev)
