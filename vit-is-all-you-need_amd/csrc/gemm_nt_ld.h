@@ -92,6 +92,8 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const GemmNtArgs p) {
     // instruction is issued, nothing is fetched; dbg bit 1 = no request instructions at all)
     bool live = true;
     unsigned so = 0u, soA = 0u, soB = 0u, par = 0u;
+    // (a K loop that starts at a different K-tile per row panel - so that the CUs of different panels do not ask L2 for the same B lines at the same moment - was
+    // measured equal: 1 308 against 1 296 us per layer, profiles/r04/nt_loader_k_rotation.log; removed)
     // (cache policies on these requests - nt, sc1, sc0 sc1 - were measured in round 4: sc1 equal, nt and sc0 sc1 3-8 % slower, and the two extra scalar
     // branches per request that selecting them at run time cost made the whole kernel 20-40 % slower: the loaders' issue loop is on every barrier's
     // critical path; profiles/r04/nt_loader_cache_policy.log)
