@@ -73,6 +73,28 @@ def test_transformer_tiny_vs_reference_golden(hip, name):
         assert O.rel_l2(grads[k], gk) < 5.7e-3, k
 
 
+def test_deferred_residual_is_bit_identical_to_the_fused_epilogue(hip):
+    """functions.DEFER_RESID (round 3): inside a stack fc2 writes bf16 y and the NEXT layer's first LayerNorm forms x2 = x1 + y - claimed to be the
+    very fp32 + bf16 sum the fused fc2 epilogue formed.  Pinned here: output, input gradient and every parameter gradient of a 2-layer stack
+    are torch.equal with the switch on and off (weight gradients come from the bitwise-reproducible split-K reduce pass, bias gradients from atomics
+    whose order may differ: those to 1e-6)."""
+    from vitamd import functions as F
+    g = load_golden("transformer_tiny.pt")
+    keep = F.DEFER_RESID
+    try:
+        runs = {}
+        for flag in (True, False):
+            F.DEFER_RESID = flag
+            y, dx, grads, _, _ = _run_transformer(g)
+            runs[flag] = (y, dx, grads)
+    finally:
+        F.DEFER_RESID = keep
+    assert torch.equal(runs[True][0], runs[False][0]) and torch.equal(runs[True][1], runs[False][1])
+    for k in runs[True][2]:
+        a, b = runs[True][2][k], runs[False][2][k]
+        assert torch.equal(a, b) if a.dim() == 2 else O.rel_l2(a, b) < 1e-6, k
+
+
 def test_transformer_layer_b_vs_reference_golden(hip):
     g = load_golden("transformer_layer_b.pt")
     y, dx, grads, _, _ = _run_transformer(g)
