@@ -441,13 +441,25 @@ def main():
             "final_loss": round(loss_val, 4), "dist": dist_info,
             "nt_seam_probe": __import__("vitamd.ops", fromlist=["SEAM_PROBE"]).SEAM_PROBE.get(dev.index),     # start-up A/B of the seam form on this device (vitamd.ops.seam_probe)
         }
-        out["device"] = box_identity(dev)
+        try:                                   # side information must never cost the headline line
+            out["device"] = box_identity(dev)
+        except Exception as e:                 # noqa: BLE001
+            out["device"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_also:
-            out["also"] = also_models(dev)
+            try:
+                out["also"] = also_models(dev)
+            except Exception as e:             # noqa: BLE001
+                out["also"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_roofline:
-            out["roofline"] = kernel_roofline(dev)
+            try:
+                out["roofline"] = kernel_roofline(dev)
+            except Exception as e:             # noqa: BLE001
+                out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:             # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
