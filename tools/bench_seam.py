@@ -18,7 +18,7 @@ wqkv_t, w1_t, w2_t = rb(D, 3 * D, scale=0.03), rb(D, 4 * D, scale=0.03), rb(4 * 
 b3, b4, b1 = torch.randn(3 * D, device=dev), torch.randn(4 * D, device=dev), torch.randn(D, device=dev)
 calls = [
     ("qkv", lambda t: ops.gemm_nt(x1, wqkv, ops.EPI_BIAS_BF16, bias=b3, tile=t), 2.0 * M * D * 3 * D, (0, 1024, 24, 25, 30, 2048)),
-    ("fc1+gelu", lambda t: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4, tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 25, 30, 2048)),
+    ("fc1+gelu", lambda t: ops.gemm_nt(x1, w1, ops.EPI_GELU_DG, bias=b4, tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 2048)),            # (320-row seam kernel: plain-bias epilogue only)
     ("dgrad_fc2", lambda t: ops.gemm_nt(x1, w2_t, ops.EPI_DMUL, aux=x4, colsum=torch.zeros(4 * D, device=dev), tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 2048)),
     ("dgrad_fc1", lambda t: ops.gemm_nt(x4, w1_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 4 * D, (0, 1024, 24, 25, 30, 2048)),
     ("dgrad_qkv", lambda t: ops.gemm_nt(x3, wqkv_t, ops.EPI_BIAS_BF16, tile=t), 2.0 * M * D * 3 * D, (0, 1024, 24, 25, 30, 2048)),
