@@ -121,7 +121,7 @@ def _run_classifier(g):
     loss = torch.nn.functional.cross_entropy(logits, labels)
     loss.backward()
     torch.cuda.synchronize()
-    return logits.detach().cpu(), float(loss), {k: p.grad.cpu() for k, p in m.named_parameters()}, m
+    return logits.detach().cpu(), float(loss.detach()), {k: p.grad.cpu() for k, p in m.named_parameters()}, m
 
 
 @pytest.mark.parametrize("name", ["vit_s32.pt", "vit_b224.pt"])  # BASELINE configs[0] and the configs[1] shape
@@ -272,7 +272,7 @@ def test_tokenizer_vs_reference_golden(hip, name):
     assert agree >= min(floor["index_agreement"], 1.0) - 0.03, agree   # nearest-code decisions may flip on near-ties
     assert abs(float(qloss) - g["quantize_loss"]) < 2e-3
     loss = torch.nn.functional.mse_loss(recon, images) + qloss
-    assert abs(float(loss) - g["loss"]) < 5e-3
+    assert abs(float(loss.detach()) - g["loss"]) < 5e-3
     loss.backward()
     torch.cuda.synchronize()
     bad = []
